@@ -1,0 +1,136 @@
+"""ctypes binding of oracle/liboracle.so (the CPU oracle; test infrastructure only)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+
+INT, LONG, FLOAT, DOUBLE, STRING = 1, 2, 3, 4, 5
+PLAIN, DELTA, RLE, SIMPLE_DICT, DICT, DICT_COMPRESS = 1, 2, 3, 4, 5, 6
+BUFFER_OVERFLOW, DATA_CORRUPTED, DATA_IMPROPER, BUG = -1, -2, -3, -100
+
+
+def _build_if_needed():
+    if not os.path.exists(LIB_PATH) and os.path.exists(os.path.join(ORACLE_DIR, "Makefile")):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+
+
+_build_if_needed()
+lib = C.CDLL(LIB_PATH)
+
+_u8p = C.POINTER(C.c_uint8)
+
+
+def _p(a):
+    """pointer to the bytes of a numpy array / bytes-like"""
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(_u8p)
+    if isinstance(a, (bytes, bytearray)):  # the caller keeps `a` alive for the duration of the call
+        return np.frombuffer(a, dtype=np.uint8).ctypes.data_as(_u8p) if len(a) else C.cast(None, _u8p)
+    raise TypeError(type(a))
+
+
+for name, res, args in [
+    ("ixo_pack_ints", C.c_int, [C.c_int, C.c_int, _u8p, _u8p]),
+    ("ixo_unpack_ints", C.c_int, [C.c_int, C.c_int, _u8p, _u8p]),
+    ("ixo_pack_longs", C.c_int, [C.c_int, C.c_int, _u8p, _u8p]),
+    ("ixo_unpack_longs", C.c_int, [C.c_int, C.c_int, _u8p, _u8p]),
+    ("ixo_delta_encode_ints", C.c_int, [C.c_int, _u8p, _u8p, C.c_int]),
+    ("ixo_delta_decode_ints", C.c_int, [C.c_int, _u8p, C.c_int, _u8p]),
+    ("ixo_delta_encode_longs", C.c_int, [C.c_int, _u8p, _u8p, C.c_int]),
+    ("ixo_delta_decode_longs", C.c_int, [C.c_int, _u8p, C.c_int, _u8p]),
+    ("ixo_delta_encode_strings", C.c_int, [C.c_int, _u8p, _u8p, C.c_int]),
+    ("ixo_delta_decode_strings", C.c_int, [C.c_int, _u8p, C.c_int, _u8p, C.c_int]),
+    ("ixo_rle_encode_ints", C.c_int, [C.c_int, C.c_int, _u8p, _u8p, C.c_int]),
+    ("ixo_rle_decode_ints", C.c_int, [C.c_int, C.c_int, _u8p, C.c_int, _u8p]),
+    ("ixo_dict_encode", C.c_int, [C.c_int, C.c_float, C.c_int, _u8p, _u8p, C.c_int]),
+    ("ixo_data_from_dict_struct", C.c_int, [C.c_int, C.c_int, _u8p, C.c_int, _u8p, C.c_int]),
+    ("ixo_dict_struct_compress", C.c_int, [C.c_int, C.c_int, _u8p, _u8p, C.c_int]),
+    ("ixo_dict_struct_decompress", C.c_int, [C.c_int, C.c_int, _u8p, C.c_int, _u8p, C.c_int]),
+    ("ixo_dict_struct_size", C.c_int, [C.c_int, _u8p]),
+    ("ixo_simple_dict_encode", C.c_int, [C.c_int, C.c_int, _u8p, _u8p, C.c_int]),
+    ("ixo_compress_pack", C.c_int, [C.c_int, C.c_int, C.c_int, _u8p, C.c_int, _u8p, C.c_int, C.POINTER(C.c_int)]),
+    ("ixo_compress_pack_as", C.c_int, [C.c_int, C.c_int, C.c_int, _u8p, C.c_int, _u8p, C.c_int]),
+    ("ixo_decompress_pack", C.c_int, [C.c_int, C.c_int, C.c_int, _u8p, C.c_int, _u8p, C.c_int]),
+    ("ixo_get_dict_struct", C.c_int, [C.c_int, C.c_int, _u8p, C.c_int, _u8p, C.c_int]),
+]:
+    fn = getattr(lib, name)
+    fn.restype = res
+    fn.argtypes = args
+
+
+class PackDesc(C.Structure):
+    _fields_ = [("in_off", C.c_uint64), ("out_off", C.c_uint64), ("pack_size", C.c_int32), ("data_size", C.c_int32),
+                ("obj_count", C.c_int32), ("encode_type", C.c_int32), ("data_type", C.c_int32), ("status", C.c_int32)]
+
+
+lib.ixo_decode_batch.restype = C.c_int
+lib.ixo_decode_batch.argtypes = [C.POINTER(PackDesc), C.c_int, _u8p, _u8p, C.c_int]
+
+
+# ---------------------------------------------------------------- convenience wrappers (numpy in / numpy out)
+def rows_to_bytes(rows, data_type):
+    """rows: numpy array (numbers) or list of bytes (strings) -> decoded-pack bytes (np.uint8)."""
+    if data_type == STRING:
+        offs = np.zeros(len(rows) + 1, dtype="<i4")
+        if len(rows):
+            offs[1:] = np.cumsum([len(s) for s in rows])
+        return np.concatenate([offs.view(np.uint8), np.frombuffer(b"".join(rows), dtype=np.uint8)])
+    dt = {INT: "<i4", LONG: "<i8", FLOAT: "<f4", DOUBLE: "<f8"}[data_type]
+    return np.ascontiguousarray(np.asarray(rows, dtype=dt)).view(np.uint8).copy()
+
+
+def bytes_to_strings(buf, n):
+    buf = np.asarray(buf, dtype=np.uint8)
+    offs = buf[:4 * (n + 1)].view("<i4")
+    body = buf[4 * (n + 1):].tobytes()
+    return [body[offs[i]:offs[i + 1]] for i in range(n)]
+
+
+def compress_pack(data, data_type, n, is_indexed=False):
+    """-> (pack bytes np.uint8, encode_type)"""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    limit = len(data) + 4 * n + 4096
+    out = np.zeros(limit, dtype=np.uint8)
+    et = C.c_int(0)
+    sz = lib.ixo_compress_pack(data_type, int(is_indexed), n, _p(data), len(data), _p(out), limit, C.byref(et))
+    if sz < 0:
+        raise RuntimeError("oracle compress failed: %d" % sz)
+    return out[:sz].copy(), et.value
+
+
+def compress_pack_as(data, data_type, n, encode_type):
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    limit = 2 * len(data) + 4 * n + 4096
+    out = np.zeros(limit, dtype=np.uint8)
+    sz = lib.ixo_compress_pack_as(data_type, encode_type, n, _p(data), len(data), _p(out), limit)
+    if sz < 0:
+        raise RuntimeError("oracle compress_as failed: %d" % sz)
+    return out[:sz].copy()
+
+
+def decompress_pack(pack, data_type, encode_type, n, data_size):
+    """-> (decoded bytes np.uint8, consumed-or-error)"""
+    pack = np.ascontiguousarray(pack, dtype=np.uint8)
+    out = np.zeros(max(data_size, 1), dtype=np.uint8)
+    r = lib.ixo_decompress_pack(data_type, encode_type, n, _p(pack), len(pack), _p(out), data_size)
+    return out[:data_size], r
+
+
+def get_dict_struct(pack, data_type, n):
+    pack = np.ascontiguousarray(pack, dtype=np.uint8)
+    size = int(pack[:4].view("<i4")[0])
+    out = np.zeros(max(size, 8), dtype=np.uint8)
+    r = lib.ixo_get_dict_struct(data_type, n, _p(pack), len(pack), _p(out), size)
+    return out[:size], r
+
+
+def data_from_dict_struct(ds, data_type, n, data_size):
+    ds = np.ascontiguousarray(ds, dtype=np.uint8)
+    out = np.zeros(max(data_size, 1), dtype=np.uint8)
+    r = lib.ixo_data_from_dict_struct(data_type, n, _p(ds), len(ds), _p(out), data_size)
+    return out[:data_size], r
