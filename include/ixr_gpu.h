@@ -1,0 +1,151 @@
+/*
+ * ixr_gpu.h -- C ABI of libixrgpu: IndexR VLT pack decode on AMD Instinct MI355X (gfx950).
+ *
+ * This is the boundary a JVM binding (JNI / Panama), a C++ host or a ctypes caller links against.  Signatures use
+ * plain pointers and sizes only.  Citations name the reference interface each entry point replaces; paths are
+ * relative to the reference tree (shunfei/indexr v0.6.1).
+ *
+ * Conventions shared with the reference:
+ *   - everything is little-endian, native order (indexr-common/.../util/ByteBufferUtil.java:31-36);
+ *   - decode functions return the number of compressed bytes consumed, or a negative ErrorCode
+ *     (indexr-vlt-segment/.../codec/Decoder.java:3-25, .../codec/ErrorCode.java:4-7); the caller checks
+ *     consumed == dpn.packSize exactly as PackCompressor_VLT.decompress does (:168);
+ *   - the caller allocates the output of exactly dpn.dataSize bytes (PackCompressor_VLT.java:133).
+ * All entry points are thread-safe and re-entrant; state is per plan / per call.
+ */
+#ifndef IXR_GPU_H
+#define IXR_GPU_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* io.indexr.segment.ColumnType / io.indexr.data.DataType ids (indexr-common/.../data/DataType.java:4-8) */
+enum { IXR_INT = 1, IXR_LONG = 2, IXR_FLOAT = 3, IXR_DOUBLE = 4, IXR_STRING = 5 };
+/* dpn.encodeType values that appear on disk (indexr-vlt-segment/.../codec/CodecType.java:4-10); 0 = the pack is stored
+ * uncompressed (dpn.compress == false: DataPack.java:180-182, FAST mode SegmentMode.java:17) */
+enum { IXR_ENC_RAW = 0, IXR_ENC_DELTA = 2, IXR_ENC_SIMPLE_DICT = 4, IXR_ENC_DICT_COMPRESS = 6 };
+/* ErrorCode.java:4-7 plus library-level failures (<= -1000) */
+enum {
+    IXR_ERR_BUFFER_OVERFLOW = -1,
+    IXR_ERR_DATA_CORRUPTED = -2,
+    IXR_ERR_DATA_IMPROPER = -3,
+    IXR_ERR_BUG = -100,
+    IXR_ERR_ILLEGAL_ENCODE_TYPE = -101, /* RuntimeException("Illegal encode type") PackCompressor_VLT.java:146 */
+    IXR_ERR_UNSUPPORTED_TYPE = -102,    /* RuntimeException("Unsupported data type") :166 */
+    IXR_ERR_INVALID_ARGUMENT = -1000,
+    IXR_ERR_NO_DEVICE = -1001, /* no usable gfx950 device / HIP runtime failure; never a silent CPU fallback */
+    IXR_ERR_HIP = -1002,
+    IXR_ERR_OUT_OF_MEMORY = -1003
+};
+
+/* Fixed geometry of the format (indexr-segment/.../pack/DataPack.java:36-38) */
+#define IXR_PACK_MAX_ROWS 65536
+/* Readable slack the library needs after the last byte of every compressed pack inside a device input arena. */
+#define IXR_IN_SLACK 16
+/* Alignment required of in_off / out_off inside the arenas. */
+#define IXR_ARENA_ALIGN 16
+
+/*
+ * One pack of work: the subset of DataPackNode_VLT (indexr-vlt-segment/.../segment/pack/DataPackNode_VLT.java:12-102;
+ * objCount@0, compress@4, packSize@13, encodeType@57, dataSize@61) the decoder needs, the column's data type (from the
+ * segment schema) and where the pack's bytes live inside the caller's input / output arenas.
+ */
+typedef struct ixr_pack_desc {
+    uint64_t in_off;      /* offset of the compressed pack in the input arena, multiple of IXR_ARENA_ALIGN */
+    uint64_t out_off;     /* offset of the decoded pack in the output arena, multiple of IXR_ARENA_ALIGN */
+    int32_t  pack_size;   /* dpn.packSize  */
+    int32_t  data_size;   /* dpn.dataSize  */
+    int32_t  obj_count;   /* dpn.objCount, 1..65536 */
+    int32_t  encode_type; /* dpn.encodeType id, or IXR_ENC_RAW when dpn.compress is false */
+    int32_t  data_type;   /* IXR_INT .. IXR_STRING */
+    int32_t  reserved;
+} ixr_pack_desc;
+
+/* ---- library / device --------------------------------------------------------------------------------------- */
+/* Bind the calling thread's work to `device`, check it is gfx950. Returns 0 or a negative error. Idempotent. */
+int32_t ixr_init(int32_t device);
+/* Human-readable text for the last error on this thread. */
+const char* ixr_last_error(void);
+/* Number of visible devices (0 when there is no GPU / HIP runtime). */
+int32_t ixr_device_count(void);
+
+/* ---- device memory helpers (so a JVM caller needs no HIP binding of its own) ---------------------------------- */
+void*   ixr_dev_alloc(int32_t device, uint64_t bytes);
+void    ixr_dev_free(int32_t device, void* dptr);
+void*   ixr_host_alloc_pinned(uint64_t bytes);
+void    ixr_host_free_pinned(void* hptr);
+int32_t ixr_memcpy_h2d(int32_t device, void* dst_dev, const void* src_host, uint64_t bytes);
+int32_t ixr_memcpy_d2h(int32_t device, void* dst_host, const void* src_dev, uint64_t bytes);
+int32_t ixr_dev_synchronize(int32_t device);
+
+/* ---- batch decode, device resident (the hot path) -------------------------------------------------------------
+ * A plan is built once per set of pack descriptors (DPN metadata is loaded when a segment is opened:
+ * indexr-segment/.../storage/StorageColumn.java:47-67); it owns the device copy of the descriptors, the work lists and
+ * the scratch memory.  ixr_plan_run decodes every pack of the plan: compressed bytes are read from `d_in`
+ * (in_off/pack_size), decoded packs are written to `d_out` (out_off/data_size).  It replaces, for many packs at once,
+ *   DataPack.decompress              indexr-segment/.../pack/DataPack.java:166-186
+ *   PackCompressor_VLT.decompress    indexr-vlt-segment/.../segment/pack/PackCompressor_VLT.java:130-170
+ *   getDictStruct + getDataFromDictStruct (the dictionary path)   :172-213
+ * `stream` is a hipStream_t (NULL = the default stream); the call only enqueues work.  The input arena must be
+ * readable for IXR_IN_SLACK bytes past every pack (ixr_plan_in_bytes accounts for it).
+ */
+typedef struct ixr_plan ixr_plan;
+/* scratch_budget_bytes: upper bound for the plan's scratch memory (0 = default 8 GiB); packs are processed in
+ * groups that fit.  Returns NULL on error (see ixr_last_error). */
+ixr_plan* ixr_plan_create(int32_t device, const ixr_pack_desc* descs, int32_t n_packs, uint64_t scratch_budget_bytes);
+void      ixr_plan_destroy(ixr_plan* plan);
+/* Minimum sizes of the arenas implied by the descriptors (max(in_off+pack_size)+slack, max(out_off+data_size)). */
+uint64_t  ixr_plan_in_bytes(const ixr_plan* plan);
+uint64_t  ixr_plan_out_bytes(const ixr_plan* plan);
+uint64_t  ixr_plan_scratch_bytes(const ixr_plan* plan);
+int32_t   ixr_plan_run(ixr_plan* plan, const void* d_in, uint64_t in_bytes, void* d_out, uint64_t out_bytes, void* stream);
+/* Copies the per-pack results of the last run to `status` (n_packs entries: bytes consumed, or a negative error);
+ * synchronises with `stream`. Returns the number of packs whose status != pack_size. */
+int32_t   ixr_plan_status(ixr_plan* plan, int32_t* status, void* stream);
+/* Algorithmic bytes of the plan: sum(pack_size) and sum(data_size); rows = sum(obj_count). */
+void      ixr_plan_totals(const ixr_plan* plan, uint64_t* in_bytes, uint64_t* out_bytes, uint64_t* rows);
+/* Names and accumulated device time (ms, measured with HIP events on `stream` when profiling was enabled with
+ * ixr_plan_set_profiling) of the kernels of the last run; returns the number of entries written (<= cap). */
+void      ixr_plan_set_profiling(ixr_plan* plan, int32_t enabled);
+int32_t   ixr_plan_kernel_times(ixr_plan* plan, const char** names, float* ms, int32_t* launches, int32_t cap);
+
+/* ---- dictionary form on device ------------------------------------------------------------------------------------
+ * Replaces PackCompressor_VLT.getDictStruct (:172-186) for every DICT_COMPRESS pack of the plan: writes the
+ * uncompressed DictStruct (indexr-common/.../data/DictStruct.java:14-55:  entryCount | entries | 4n | ids) of pack i at
+ * d_out + ds_off[i]; ds_off are byte offsets supplied by the caller (multiples of IXR_ARENA_ALIGN), each region holding
+ * at least the pack's dictStructSize (its first 4 bytes).  Packs of other encodings are skipped.
+ */
+int32_t   ixr_plan_run_dict_structs(ixr_plan* plan, const void* d_in, uint64_t in_bytes, void* d_out, uint64_t out_bytes,
+                                    const uint64_t* ds_off, void* stream);
+
+/* ---- single pack, host memory in / host memory out ---------------------------------------------------------------
+ * Same contract as the reference's Decoder.decodeInts|Longs|Floats|Doubles|Strings(valCount, inputAddr, outputAddr,
+ * outputLimit) (Decoder.java:5-25) dispatched like PackCompressor_VLT.decompress (:130-170).  Copies the pack to the
+ * device, decodes it there, copies the result back.  Meant for parity tests and small callers; engines should batch.
+ */
+int32_t ixr_decode_pack(int32_t device, int32_t data_type, int32_t encode_type, int32_t obj_count,
+                        const void* in, int32_t in_size, void* out, int32_t out_limit);
+/* PackCompressor_VLT.getDictStruct (:172-186): `in` is the whole pack; out receives dictStructSize bytes. */
+int32_t ixr_get_dict_struct(int32_t device, int32_t data_type, int32_t obj_count,
+                            const void* in, int32_t in_size, void* out, int32_t out_limit);
+/* PackCompressor_VLT.getDataFromDictStruct (:188-213) / DictStruct.decodeXxx (DictStruct.java:57-110): gather the rows
+ * out of an uncompressed DictStruct. Returns bytes written or a negative error. */
+int32_t ixr_get_data_from_dict_struct(int32_t device, int32_t data_type, int32_t obj_count,
+                                      const void* dict_struct, int32_t ds_size, void* out, int32_t out_limit);
+
+/* ---- host-side write path (needed to build inputs; CPU only) --------------------------------------------------------
+ * PackCompressor_VLT.compress (:23-128): codec choice and encoding of one pack. `data` is the decoded pack
+ * (numbers: raw LE array; strings: StringsStruct, indexr-common/.../data/StringsStruct.java:12-17).
+ * Returns the compressed size or a negative error; *encode_type receives the CodecType id.
+ */
+int32_t ixr_compress_pack(int32_t data_type, int32_t is_indexed, int32_t obj_count, const void* data, int32_t data_size,
+                          void* out, int32_t out_limit, int32_t* encode_type);
+/* Upper bound for the compressed size (Codec.outputBufferSize, indexr-vlt-segment/.../codec/Codec.java:7-27). */
+int32_t ixr_compress_bound(int32_t obj_count, int32_t data_size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IXR_GPU_H */

@@ -1,0 +1,71 @@
+// ixr_device.h -- structures shared by the host side of libixrgpu and its HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ixr {
+
+// Geometry of the VLT DELTA codec (indexr-vlt-segment/.../codec/delta/DeltaCodec.java:31-32) and of the RLE tiling.
+constexpr int kBlock = 128;        // values per delta block (one zig-zag varint minDelta each)
+constexpr int kMini = 32;          // values per mini-block (one width byte each)
+constexpr int kRleTile = 1024;     // rows per RLE restart point / per wave tile in the id-expanding kernels
+constexpr int kStrTileRows = 256;  // rows per workgroup tile in the string body copy
+
+// Element stride of the per-pack string length arrays (prefixLen / suffixLen / sufOff): obj_count rounded up to 4 so that
+// each array starts 16-byte aligned.
+__host__ __device__ inline uint32_t lens_stride(int32_t obj_count) { return ((uint32_t)obj_count + 4u) & ~3u; }
+
+// What the parse kernel found a pack to be.
+enum PackKind : int32_t {
+    K_NONE = 0,
+    K_RAW = 1,        // stored uncompressed: copy
+    K_DELTA_NUM = 2,  // DELTA over int32/int64 bit patterns, decoded straight into the output
+    K_DICT_NUM = 3,   // DICT_COMPRESS or SIMPLE_DICT, numeric
+    K_DICT_STR = 4,   // DICT_COMPRESS or SIMPLE_DICT, strings
+    K_DELTA_STR = 5,  // whole pack front coded (DELTA on strings)
+};
+
+// One pack as the kernels see it: the caller's descriptor plus scratch offsets (relative to the group's scratch base)
+// laid out by the host from obj_count / data_size alone.
+struct DevPack {
+    uint64_t in_off;
+    uint64_t out_off;
+    int32_t pack_size;
+    int32_t data_size;
+    int32_t obj_count;
+    int32_t encode_type;
+    int32_t data_type;
+    int32_t width;       // 32 / 64 for numbers, 0 for strings
+    uint64_t s_idx[2];   // DELTA index of stream 0 / 1:  int64 minDelta[ceil(cap/128)] | uint32 mb[ceil(cap/32)]
+    uint64_t s_dict;     // decoded dictionary, aligned: numbers entryCount*w ; strings a StringsStruct
+    uint64_t dict_cap;   // bytes available at s_dict
+    uint64_t s_restart;  // RLE restart points: uint2[ceil(cap/kRleTile)] = (header offset in pack, first row of segment)
+    uint64_t s_lens;     // strings: int32 prefixLen[S] | int32 suffixLen[S] | uint32 sufOff[S], S = lens_stride(obj_count) >= cap+1
+    uint64_t s_rows;     // strings: uint32 srcOff[cap] (offset of each row's bytes inside the dictionary body)
+    uint64_t ds_off;     // only for the getDictStruct run: where to write the DictStruct in the output arena
+};
+
+struct StreamDesc {
+    uint32_t n;       // values in the stream (0 = absent)
+    uint32_t in_off;  // offset of the stream's 4-byte length word, relative to the pack
+    int64_t first;    // first value (zig-zag decoded)
+};
+
+// Written by the parse kernel, read by every later kernel.
+struct PackMeta {
+    int32_t status;         // bytes consumed, or a negative error code
+    int32_t kind;           // PackKind
+    uint32_t entry_count;   // dictionary entries
+    uint32_t id_bw;         // bit width of the ids = bitWidth(entryCount - 1)
+    uint32_t ids_off;       // offset of the RLE stream's length word in the pack
+    uint32_t ids_len;       // its encodedLen
+    uint32_t entries_off;   // offset of plain (uncompressed) entries in the pack
+    uint32_t entries_plain; // 1: entries are stored plain at entries_off
+    uint32_t sfx_off;       // front coding: offset of the suffix bytes in the pack
+    uint32_t sfx_len;       // front coding: number of suffix bytes the headers promise
+    uint32_t dict_struct_size; // DICT_COMPRESS: the 4-byte uncompressed DictStruct size at the head of the pack
+    uint32_t max_len;       // strings: longest dictionary entry (filled by the dictionary scan)
+    StreamDesc s[2];
+};
+
+}  // namespace ixr

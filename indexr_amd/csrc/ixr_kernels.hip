@@ -1,0 +1,1064 @@
+// ixr_kernels.hip -- CDNA4 (gfx950) kernels decoding IndexR VLT packs.  Wave size is 64 throughout.
+//
+// Wire format decoded here (all little-endian), with the reference routine each kernel replaces:
+//   bit packing     value i of a run sits at bit i*bw of the byte string         IntPacker.java:54-70, LongPacker.java:54-71
+//   DELTA numbers   u32 len | zz-varint first | per 128: zz-varint minDelta,    DeltaCodec.java:100-141, 204-245
+//                   per 32: u8 bw + ceil(c/8)*bw bytes ; v = prev + minDelta + packed (wrapping)
+//   RLE hybrid ids  u32 len | { uvarint h ; h&1 ? (h>>1) packed values : run of (h>>1) x fixed-width value }*
+//                                                                                RLEPackingHybridCodec.java:97-128
+//   DICT_COMPRESS   u32 dictStructSize | u32 entryCount | u8 compressed | entries | ids   DictStructUtil.java:83-142
+//   SIMPLE_DICT     u32 entryCount | plain entries | u32 dataSize | ids                   SimpleDictCodec.java:131-159 ...
+//   DELTA strings   u32 len | DELTA(prefixLen) | DELTA(suffixLen) | suffix bytes          DeltaCodec.java:355-388
+//   decoded strings int32 offset[n+1] | bodies                                            StringsStruct.java:12-17
+// (paths relative to indexr-vlt-segment/src/main/java/io/indexr/vlt/codec/ and indexr-common/.../data/ of the reference)
+//
+// Pipeline per group of packs (one launch each, thousands of packs per launch):
+//   k_parse      one lane per serial stream: walks the data-dependent framing (mini-block widths, RLE headers), validates
+//                it and leaves an index: per mini-block (offset,width), per block minDelta, per 1024-row tile an RLE
+//                restart point.  Many independent chains per wave hide the load latency of each chain.
+//   k_delta      one workgroup per DELTA stream: bit-unpack + wave/workgroup prefix sum with a running carry.
+//   k_dict_num   one wave per 1024-row tile: expand ids from the restart point, gather dictionary entries, store rows.
+//   string packs k_str_dict_scan -> k_front_decode -> k_str_rows -> k_row_scan -> k_str_copy  (see each kernel)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ixr_device.h"
+#include "ixr_launch.h"
+
+namespace ixr {
+
+// error codes (mirror include/ixr_gpu.h)
+constexpr int32_t E_OVERFLOW = -1, E_CORRUPT = -2, E_ILLEGAL_ENC = -101, E_UNSUPPORTED = -102;
+
+// ---------------------------------------------------------------------------------------------------------------
+// unaligned little-endian access built from aligned dword loads (the arena is readable 16 bytes past every pack)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ld8(const uint8_t* p) { return *p; }
+
+__device__ __forceinline__ uint32_t ld32u(const uint8_t* p) {
+    uintptr_t a = (uintptr_t)p;
+    const uint32_t* q = (const uint32_t*)(a & ~(uintptr_t)3);
+    uint32_t sh = (uint32_t)(a & 3) << 3;
+    uint64_t w = (uint64_t)q[0] | ((uint64_t)q[1] << 32);
+    return (uint32_t)(w >> sh);
+}
+
+// bits [bit, bit+bw) of the little-endian bit string starting at `base`; bw in 0..32
+__device__ __forceinline__ uint32_t extract32(const uint8_t* base, uint32_t bit, uint32_t bw) {
+    uintptr_t a = (uintptr_t)(base + (bit >> 3));
+    const uint32_t* q = (const uint32_t*)(a & ~(uintptr_t)3);
+    uint32_t sh = ((uint32_t)(a & 3) << 3) + (bit & 7);  // 0..31
+    uint64_t w = (uint64_t)q[0] | ((uint64_t)q[1] << 32);
+    uint32_t v = (uint32_t)(w >> sh);
+    return bw >= 32 ? v : (v & ((1u << bw) - 1u));
+}
+
+// bw in 0..64
+__device__ __forceinline__ uint64_t extract64(const uint8_t* base, uint32_t bit, uint32_t bw) {
+    uintptr_t a = (uintptr_t)(base + (bit >> 3));
+    const uint32_t* q = (const uint32_t*)(a & ~(uintptr_t)3);
+    uint32_t sh = ((uint32_t)(a & 3) << 3) + (bit & 7);  // 0..31
+    uint64_t lo = (uint64_t)q[0] | ((uint64_t)q[1] << 32);
+    uint64_t hi = q[2];
+    uint64_t v = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+    return bw >= 64 ? v : (v & ((1ull << bw) - 1ull));
+}
+
+template <typename U> __device__ __forceinline__ U extract(const uint8_t* base, uint32_t bit, uint32_t bw);
+template <> __device__ __forceinline__ uint32_t extract<uint32_t>(const uint8_t* base, uint32_t bit, uint32_t bw) { return extract32(base, bit, bw); }
+template <> __device__ __forceinline__ uint64_t extract<uint64_t>(const uint8_t* base, uint32_t bit, uint32_t bw) { return extract64(base, bit, bw); }
+
+__device__ __forceinline__ uint32_t bit_width32(uint32_t v) { return v ? 32u - (uint32_t)__clz((int)v) : 0u; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_parse: serial framing walk, one lane per stream (4 lanes per pack: DELTA stream 0, DELTA stream 1, RLE ids, spare)
+// ---------------------------------------------------------------------------------------------------------------
+struct Walker {
+    const uint8_t* base;  // pack start
+    uint32_t pos;         // current offset in the pack
+    uint32_t end;         // one past the last readable offset of the current stream
+    int32_t err;
+    __device__ __forceinline__ uint32_t u8() {
+        if (pos >= end) { err = E_CORRUPT; return 0; }
+        return base[pos++];
+    }
+    // VarInteger.readUnsignedVarInt / readUnsignedVarLong (VarInteger.java:68-96); at most 5 / 10 bytes
+    __device__ __forceinline__ uint64_t uvarint(int max_bytes) {
+        uint64_t v = 0;
+        int shift = 0;
+        for (int i = 0; i < max_bytes; i++) {
+            uint32_t b = u8();
+            v |= (uint64_t)(b & 0x7F) << shift;
+            if (!(b & 0x80)) return v;
+            shift += 7;
+        }
+        err = E_CORRUPT;
+        return v;
+    }
+};
+
+// VarInteger.readZigZagVarInt / readZigZagVarLong (VarInteger.java:106-127)
+__device__ __forceinline__ int64_t unzigzag32(uint64_t raw) {
+    uint32_t r = (uint32_t)raw;
+    return (int64_t)(int32_t)((r >> 1) ^ (0u - (r & 1u)));
+}
+__device__ __forceinline__ int64_t unzigzag64(uint64_t r) { return (int64_t)((r >> 1) ^ (0ull - (r & 1ull))); }
+
+// Walk one DELTA stream (DeltaCodec.decodeInts/decodeLongs framing, DeltaCodec.java:100-141, 204-245) and write its index.
+__device__ int32_t walk_delta(const uint8_t* base, uint32_t pack_size, uint32_t off, uint32_t n, int width,
+                              int64_t* min_delta, uint32_t* mb, int64_t* first_out, bool write) {
+    Walker w{base, off, pack_size, 0};
+    if (off + 4 > pack_size) return E_CORRUPT;
+    int32_t len = (int32_t)ld32u(base + off);
+    if (len < 0 || (uint64_t)off + 4 + (uint64_t)len > pack_size) return E_CORRUPT;
+    w.pos = off + 4;
+    w.end = off + 4 + (uint32_t)len;
+    const int vb = width == 32 ? 5 : 10;
+    uint64_t raw = w.uvarint(vb);
+    *first_out = width == 32 ? unzigzag32(raw) : unzigzag64(raw);
+    uint32_t nb = (n + kBlock - 1) / kBlock;
+    for (uint32_t b = 0; b < nb && !w.err; b++) {
+        raw = w.uvarint(vb);
+        int64_t md = width == 32 ? unzigzag32(raw) : unzigzag64(raw);
+        if (write) min_delta[b] = md;
+        uint32_t cnt = min((uint32_t)kBlock, n - b * kBlock);
+        for (uint32_t m = 0; m * kMini < cnt; m++) {
+            uint32_t c = min((uint32_t)kMini, cnt - m * kMini);
+            uint32_t bw = w.u8();
+            if (bw > (uint32_t)width) w.err = E_CORRUPT;
+            if (w.err) break;
+            if (w.pos >= (1u << 24)) { w.err = E_CORRUPT; break; }
+            if (write) mb[b * 4 + m] = w.pos | (bw << 24);
+            w.pos += ((c + 7) >> 3) * bw;
+            if (w.pos > w.end) { w.err = E_CORRUPT; break; }
+        }
+    }
+    if (!w.err && w.pos != w.end) w.err = E_CORRUPT;
+    return w.err;
+}
+
+// Walk the RLE/bit-packing hybrid id stream (RLEPackingHybridCodec.decodeInts, RLEPackingHybridCodec.java:97-128) and
+// record, for every tile of kRleTile rows, the segment header that covers the tile's first row.
+__device__ int32_t walk_rle(const uint8_t* base, uint32_t off, uint32_t len, uint32_t n, uint32_t bw, uint2* restart, bool write) {
+    Walker w{base, off + 4, off + 4 + len, 0};
+    const uint32_t bytew = (bw + 7) >> 3;
+    uint32_t o = 0, next_tile = 0;
+    while (w.pos < w.end) {
+        uint32_t hp = w.pos;
+        uint32_t h = (uint32_t)w.uvarint(5);
+        if (w.err) break;
+        uint32_t cnt = h >> 1;
+        uint64_t payload = (h & 1) ? (uint64_t)((cnt + 7) >> 3) * bw : bytew;
+        if ((uint64_t)w.pos + payload > w.end || cnt > n - o) { w.err = E_CORRUPT; break; }
+        if (cnt) {
+            while (next_tile * (uint32_t)kRleTile < o + cnt) {
+                if (write) restart[next_tile] = make_uint2(hp, o);
+                next_tile++;
+            }
+        }
+        o += cnt;
+        w.pos += (uint32_t)payload;
+    }
+    if (!w.err && o != n) w.err = E_CORRUPT;  // Preconditions.checkState(valIndex == valCount) :126
+    return w.err;
+}
+
+__global__ __launch_bounds__(256) void k_parse(const DevPack* __restrict__ packs, const int* __restrict__ list, int count,
+                                               PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
+                                               uint8_t* __restrict__ scratch) {
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    int li = tid >> 2;
+    const int k = tid & 3;
+    const bool active = li < count;
+    if (!active) li = count - 1;  // keep the lane alive for the shuffles below; its writes are suppressed
+    const int pi = list[li];
+    const DevPack P = packs[pi];
+    const uint8_t* base = in + P.in_off;
+    const uint32_t psz = (uint32_t)P.pack_size;
+    const uint32_t n = (uint32_t)P.obj_count;
+    const int W = P.width;  // 32, 64 or 0 (strings)
+
+    PackMeta m;
+    m.status = 0; m.kind = K_NONE; m.entry_count = 0; m.id_bw = 0; m.ids_off = 0; m.ids_len = 0; m.entries_off = 0;
+    m.entries_plain = 0; m.sfx_off = 0; m.sfx_len = 0; m.dict_struct_size = 0; m.max_len = 0;
+    m.s[0].n = m.s[1].n = 0; m.s[0].in_off = m.s[1].in_off = 0; m.s[0].first = m.s[1].first = 0;
+    int32_t err = 0;
+    int64_t consumed = 0;
+    bool has_ids = false;
+
+    auto rd32 = [&](uint64_t off) -> uint32_t {  // bounds-checked header read
+        if (off + 4 > psz) { if (!err) err = E_CORRUPT; return 0; }
+        return ld32u(base + off);
+    };
+
+    if (n == 0 || n > 65536u || P.pack_size < 0 || P.data_size < 0) err = E_CORRUPT;
+    if (!err) {
+        switch (P.encode_type) {
+            case 0:  // stored uncompressed (DataPack.java:180-182)
+                m.kind = K_RAW;
+                if (P.pack_size != P.data_size) err = E_OVERFLOW;
+                consumed = psz;
+                break;
+            case 2:  // DELTA
+                if (W) {
+                    if ((uint64_t)n * (W / 8) != (uint64_t)P.data_size) err = E_OVERFLOW;
+                    m.kind = K_DELTA_NUM;
+                    m.s[0].n = n; m.s[0].in_off = 0;
+                    consumed = 4 + (int64_t)(int32_t)rd32(0);
+                } else {
+                    m.kind = K_DELTA_STR;
+                    uint32_t eds = rd32(0);
+                    uint32_t l0 = rd32(4);
+                    uint64_t o1 = 8ull + l0;
+                    uint32_t l1 = rd32(o1);
+                    uint64_t so = o1 + 4 + l1;
+                    if ((int32_t)eds < 0 || (int32_t)l0 < 0 || (int32_t)l1 < 0 || so > psz || 8ull + l0 + l1 > eds) { if (!err) err = E_CORRUPT; }
+                    m.s[0].n = n; m.s[0].in_off = 4;
+                    m.s[1].n = n; m.s[1].in_off = (uint32_t)o1;
+                    m.sfx_off = (uint32_t)so;
+                    m.sfx_len = eds - (uint32_t)(8 + l0 + l1);
+                    m.entry_count = n;
+                    consumed = 4 + (int64_t)eds;
+                }
+                break;
+            case 6: {  // DICT_COMPRESS
+                m.kind = W ? K_DICT_NUM : K_DICT_STR;
+                m.dict_struct_size = rd32(0);
+                uint32_t ec = rd32(4);
+                uint32_t comp = psz > 8 ? base[8] : 0;
+                if (psz < 9 || ec == 0 || ec > n) { if (!err) err = E_CORRUPT; ec = 1; }
+                m.entry_count = ec;
+                m.id_bw = bit_width32(ec - 1);
+                uint64_t ids_off;
+                if (W) {
+                    if ((uint64_t)n * (W / 8) != (uint64_t)P.data_size) err = E_OVERFLOW;
+                    if (m.dict_struct_size != 4 + ec * (W / 8) + 4 + 4 * n && !err) err = E_CORRUPT;
+                    if (comp) {
+                        m.s[0].n = ec; m.s[0].in_off = 9;
+                        uint32_t l0 = rd32(9);
+                        if ((int32_t)l0 < 0 && !err) err = E_CORRUPT;
+                        ids_off = 13ull + l0;
+                    } else {
+                        m.entries_plain = 1; m.entries_off = 9;
+                        ids_off = 9ull + (uint64_t)ec * (W / 8);
+                    }
+                } else {
+                    if (comp) {
+                        uint32_t eds = rd32(9);
+                        uint32_t l0 = rd32(13);
+                        uint64_t o1 = 17ull + l0;
+                        uint32_t l1 = rd32(o1);
+                        uint64_t so = o1 + 4 + l1;
+                        if ((int32_t)eds < 0 || (int32_t)l0 < 0 || (int32_t)l1 < 0 || so > psz || 8ull + l0 + l1 > eds) { if (!err) err = E_CORRUPT; }
+                        m.s[0].n = ec; m.s[0].in_off = 13;
+                        m.s[1].n = ec; m.s[1].in_off = (uint32_t)o1;
+                        m.sfx_off = (uint32_t)so;
+                        m.sfx_len = eds - (uint32_t)(8 + l0 + l1);
+                        ids_off = 13ull + eds;
+                    } else {
+                        m.entries_plain = 1; m.entries_off = 9;
+                        uint32_t tot = rd32(9ull + 4ull * ec);
+                        if ((int32_t)tot < 0 && !err) err = E_CORRUPT;
+                        ids_off = 9ull + 4ull * (ec + 1) + tot;
+                    }
+                }
+                uint32_t il = rd32(ids_off);
+                if (((int32_t)il < 0 || ids_off + 4 + il > psz) && !err) err = E_CORRUPT;
+                m.ids_off = (uint32_t)ids_off; m.ids_len = il;
+                has_ids = true;
+                consumed = (int64_t)ids_off + 4 + il;
+                break;
+            }
+            case 4: {  // SIMPLE_DICT (legacy, decode only)
+                m.kind = W ? K_DICT_NUM : K_DICT_STR;
+                uint32_t ec = rd32(0);
+                if (ec == 0 || ec > n) { if (!err) err = E_CORRUPT; ec = 1; }
+                m.entry_count = ec;
+                m.id_bw = bit_width32(ec - 1);
+                m.entries_plain = 1; m.entries_off = 4;
+                uint64_t dict_size;
+                if (W) {
+                    if ((uint64_t)n * (W / 8) != (uint64_t)P.data_size) err = E_OVERFLOW;
+                    dict_size = (uint64_t)ec * (W / 8);
+                } else {
+                    uint32_t tot = rd32(4ull + 4ull * ec);
+                    if ((int32_t)tot < 0 && !err) err = E_CORRUPT;
+                    dict_size = 4ull * (ec + 1) + tot;
+                }
+                uint64_t ids_off = 4 + dict_size + 4;
+                uint32_t il = rd32(ids_off);
+                if (((int32_t)il < 0 || ids_off + 4 + il > psz) && !err) err = E_CORRUPT;
+                m.ids_off = (uint32_t)ids_off; m.ids_len = il;
+                has_ids = true;
+                consumed = (int64_t)ids_off + 4 + il;
+                break;
+            }
+            default:
+                err = E_ILLEGAL_ENC;
+        }
+    }
+    if (!err && (consumed < 0 || consumed > (int64_t)psz)) err = E_CORRUPT;
+
+    // ---- the serial walks, one per lane
+    int32_t werr = 0;
+    int64_t first = 0;
+    if (!err) {
+        const StreamDesc sd = k == 0 ? m.s[0] : m.s[1];
+        if (k < 2 && sd.n) {
+            int64_t* md = (int64_t*)(scratch + (k == 0 ? P.s_idx[0] : P.s_idx[1]));
+            uint32_t* mb = (uint32_t*)(md + (P.obj_count + kBlock - 1) / kBlock);
+            werr = walk_delta(base, psz, sd.in_off, sd.n, W ? W : 32, md, mb, &first, active);
+        } else if (k == 2 && has_ids) {
+            werr = walk_rle(base, m.ids_off, m.ids_len, n, m.id_bw, (uint2*)(scratch + P.s_restart), active);
+        }
+    }
+    // ---- lane 0 of each group of 4 collects the results and writes the meta record
+    const int lane = threadIdx.x & 63;
+    const int g0 = lane & ~3;
+    int32_t e0 = __shfl(werr, g0), e1 = __shfl(werr, g0 + 1), e2 = __shfl(werr, g0 + 2);
+    int64_t f1 = __shfl(first, g0 + 1);
+    if (active && k == 0) {
+        m.s[0].first = first;
+        m.s[1].first = f1;
+        if (!err) err = e0 ? e0 : (e1 ? e1 : e2);
+        m.status = err ? err : (int32_t)consumed;
+        metas[pi] = m;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// wave / workgroup scan helpers
+// ---------------------------------------------------------------------------------------------------------------
+template <typename U> __device__ __forceinline__ U wave_incl_scan(U v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        U t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_delta: one 256-thread workgroup per DELTA stream.  Each thread unpacks 4 consecutive values (same mini-block) per
+// iteration; a thread-local sum, a wave scan and a 4-entry LDS combine give the running values; the carry travels in a
+// register.  Replaces the two passes of DeltaCodec.decodeIntsBlock / decodeLongsBlock (DeltaCodec.java:112-127, 216-231).
+// Also copies plain (uncompressed) dictionary entries into the aligned scratch dictionary (PlainCodec.java:48-70).
+// ---------------------------------------------------------------------------------------------------------------
+template <typename U>
+__global__ __launch_bounds__(256) void k_delta(const DevPack* __restrict__ packs, const int* __restrict__ list,
+                                               const PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
+                                               uint8_t* __restrict__ out, uint8_t* __restrict__ scratch) {
+    const int pi = list[blockIdx.x];
+    const int sk = blockIdx.y;
+    const DevPack P = packs[pi];
+    const PackMeta& M = metas[pi];
+    if (M.status < 0) return;
+    const int kind = M.kind;
+    const uint8_t* base = in + P.in_off;
+    const int tid = threadIdx.x;
+
+    if (sk == 0 && M.entries_plain && kind == K_DICT_NUM) {
+        // plain numeric entries: byte-granular copy into the aligned scratch dictionary
+        const uint32_t bytes = M.entry_count * (uint32_t)sizeof(U);
+        const uint8_t* src = base + M.entries_off;
+        uint8_t* dst = scratch + P.s_dict;
+        if (((uintptr_t)src & 3) == 0) {
+            for (uint32_t i = tid; i < bytes / 4; i += 256) ((uint32_t*)dst)[i] = ((const uint32_t*)src)[i];
+        } else {
+            for (uint32_t i = tid; i < bytes; i += 256) dst[i] = src[i];
+        }
+        return;
+    }
+    const StreamDesc s = M.s[sk];
+    if (s.n == 0) return;
+
+    U* dst;
+    if (kind == K_DELTA_NUM) dst = (U*)(out + P.out_off);
+    else if (kind == K_DICT_NUM) dst = (U*)(scratch + P.s_dict);
+    else dst = (U*)(scratch + P.s_lens + (size_t)sk * 4 * (size_t)lens_stride(P.obj_count));  // string length streams (always 32 bit)
+
+    const int64_t* min_delta = (const int64_t*)(scratch + P.s_idx[sk]);
+    const uint32_t* mb = (const uint32_t*)(min_delta + (P.obj_count + kBlock - 1) / kBlock);
+    const uint32_t n = s.n;
+    const int lane = tid & 63, wave = tid >> 6;
+    __shared__ U wsum[2][4];
+    U carry = (U)s.first;
+    int buf = 0;
+    for (uint32_t c0 = 0; c0 < n; c0 += 1024, buf ^= 1) {
+        const uint32_t i0 = c0 + 4 * tid;
+        U d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+        if (i0 < n) {
+            const uint32_t hdr = mb[i0 >> 5];
+            const uint32_t bw = hdr >> 24;
+            const uint8_t* src = base + (hdr & 0xFFFFFFu);
+            const U md = (U)min_delta[i0 >> 7];
+            const uint32_t bit = (i0 & 31) * bw;
+            d0 = extract<U>(src, bit, bw) + md;
+            if (i0 + 1 < n) d1 = extract<U>(src, bit + bw, bw) + md;
+            if (i0 + 2 < n) d2 = extract<U>(src, bit + 2 * bw, bw) + md;
+            if (i0 + 3 < n) d3 = extract<U>(src, bit + 3 * bw, bw) + md;
+        }
+        d1 += d0; d2 += d1; d3 += d2;
+        const U incl = wave_incl_scan<U>(d3);
+        if (lane == 63) wsum[buf][wave] = incl;
+        __syncthreads();
+        const U w0 = wsum[buf][0], w1 = wsum[buf][1], w2 = wsum[buf][2], w3 = wsum[buf][3];
+        U wprefix = 0;
+        if (wave > 0) wprefix += w0;
+        if (wave > 1) wprefix += w1;
+        if (wave > 2) wprefix += w2;
+        const U pre = carry + wprefix + (incl - d3);
+        if (i0 + 3 < n) {
+            if constexpr (sizeof(U) == 4) {
+                *(uint4*)(dst + i0) = make_uint4(d0 + pre, d1 + pre, d2 + pre, d3 + pre);
+            } else {
+                ulonglong2* o2 = (ulonglong2*)(dst + i0);
+                o2[0] = make_ulonglong2(d0 + pre, d1 + pre);
+                o2[1] = make_ulonglong2(d2 + pre, d3 + pre);
+            }
+        } else if (i0 < n) {
+            dst[i0] = d0 + pre;
+            if (i0 + 1 < n) dst[i0 + 1] = d1 + pre;
+            if (i0 + 2 < n) dst[i0 + 2] = d2 + pre;
+        }
+        carry += w0 + w1 + w2 + w3;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// RLE tile iteration shared by the id-consuming kernels: a wave walks the segments that overlap its tile, starting
+// from the restart point the parse kernel left, and hands every (row, id) of the tile to `f`, 64 rows at a time.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename F>
+__device__ __forceinline__ void rle_tile_foreach(const uint8_t* base, const PackMeta& M, uint2 restart, uint32_t tile_start,
+                                                 uint32_t tile_end, F f) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t bw = M.id_bw;
+    const uint32_t bytew = (bw + 7) >> 3;
+    const uint32_t end = M.ids_off + 4 + M.ids_len;
+    uint32_t pos = restart.x, o = restart.y;
+    while (o < tile_end && pos < end) {
+        // uniform header parse (every lane reads the same bytes)
+        uint32_t h = 0;
+        int shift = 0;
+        for (int i = 0; i < 5 && pos < end; i++) {
+            uint32_t b = base[pos++];
+            h |= (b & 0x7F) << shift;
+            if (!(b & 0x80)) break;
+            shift += 7;
+        }
+        const uint32_t cnt = h >> 1;
+        const uint32_t lo = max(o, tile_start), hi = min(o + cnt, tile_end);
+        if (h & 1) {
+            const uint8_t* data = base + pos;
+            for (uint32_t i = lo + lane; i < hi; i += 64) f(i, extract32(data, (i - o) * bw, bw));
+            pos += ((cnt + 7) >> 3) * bw;
+        } else {
+            uint32_t val = 0;
+            for (uint32_t b = 0; b < bytew; b++) val |= (uint32_t)base[pos + b] << (8 * b);
+            for (uint32_t i = lo + lane; i < hi; i += 64) f(i, val);
+            pos += bytew;
+        }
+        o += cnt;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_dict_num: numeric dictionary packs.  One wave per tile of kRleTile rows: out[i] = dict[id[i]]
+// (DictStruct.decodeInts/Longs/Floats/Doubles, indexr-common/.../data/DictStruct.java:57-95).
+// ---------------------------------------------------------------------------------------------------------------
+template <typename U>
+__global__ __launch_bounds__(256) void k_dict_num(const DevPack* __restrict__ packs, const int* __restrict__ list,
+                                                  PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
+                                                  uint8_t* __restrict__ out, const uint8_t* __restrict__ scratch) {
+    const int pi = list[blockIdx.y];
+    const PackMeta& M = metas[pi];
+    if (M.status < 0 || M.kind != K_DICT_NUM) return;
+    const DevPack P = packs[pi];
+    const uint32_t n = (uint32_t)P.obj_count;
+    const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t tile_start = tile * kRleTile;
+    if (tile_start >= n) return;
+    const uint32_t tile_end = min(n, tile_start + (uint32_t)kRleTile);
+    const uint8_t* base = in + P.in_off;
+    const U* dict = (const U*)(scratch + P.s_dict);
+    U* dst = (U*)(out + P.out_off);
+    const uint32_t ec = M.entry_count;
+    const uint2 restart = ((const uint2*)(scratch + P.s_restart))[tile];
+    bool bad = false;
+    rle_tile_foreach(base, M, restart, tile_start, tile_end, [&](uint32_t i, uint32_t id) {
+        if (id >= ec) { bad = true; id = 0; }
+        dst[i] = dict[id];
+    });
+    if (bad) metas[pi].status = E_CORRUPT;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_copy_raw: packs stored uncompressed (DataPack.java:180-182): data = cmpData.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_copy_raw(const DevPack* __restrict__ packs, const int* __restrict__ list,
+                                                  const PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
+                                                  uint8_t* __restrict__ out) {
+    const int pi = list[blockIdx.y];
+    const PackMeta& M = metas[pi];
+    if (M.status < 0 || M.kind != K_RAW) return;
+    const DevPack P = packs[pi];
+    const uint32_t bytes = (uint32_t)P.pack_size;
+    const uint4* src = (const uint4*)(in + P.in_off);
+    uint4* dst = (uint4*)(out + P.out_off);
+    const uint32_t nvec = bytes >> 4;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nvec; i += gridDim.x * 256) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x < (bytes & 15)) {
+        const uint32_t o = (nvec << 4) + threadIdx.x;
+        out[P.out_off + o] = in[P.in_off + o];
+    }
+}
+
+// ===============================================================================================================
+// strings
+// ===============================================================================================================
+
+// Generic workgroup exclusive scan over `n` uint32 produced by `get(i)`, handing (i, exclusive prefix, value) to `put`;
+// returns the grand total to every thread.  256 threads, 4 items per thread and iteration.
+template <typename G, typename Pf>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t n, G get, Pf put) {
+    __shared__ uint32_t wsum[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t carry = 0;
+    int buf = 0;
+    for (uint32_t c0 = 0; c0 < n; c0 += 1024, buf ^= 1) {
+        const uint32_t i0 = c0 + 4 * tid;
+        uint32_t v0 = i0 < n ? get(i0) : 0, v1 = i0 + 1 < n ? get(i0 + 1) : 0, v2 = i0 + 2 < n ? get(i0 + 2) : 0,
+                 v3 = i0 + 3 < n ? get(i0 + 3) : 0;
+        const uint32_t t = v0 + v1 + v2 + v3;
+        const uint32_t incl = wave_incl_scan<uint32_t>(t);
+        if (lane == 63) wsum[buf][wave] = incl;
+        __syncthreads();
+        const uint32_t w0 = wsum[buf][0], w1 = wsum[buf][1], w2 = wsum[buf][2], w3 = wsum[buf][3];
+        uint32_t pre = carry + (incl - t);
+        if (wave > 0) pre += w0;
+        if (wave > 1) pre += w1;
+        if (wave > 2) pre += w2;
+        if (i0 < n) put(i0, pre, v0);
+        if (i0 + 1 < n) put(i0 + 1, pre + v0, v1);
+        if (i0 + 2 < n) put(i0 + 2, pre + v0 + v1, v2);
+        if (i0 + 3 < n) put(i0 + 3, pre + v0 + v1 + v2, v3);
+        carry += w0 + w1 + w2 + w3;
+    }
+    return carry;
+}
+
+__device__ __forceinline__ uint32_t block_max(uint32_t v) {
+    __shared__ uint32_t mx[4];
+    for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
+    if ((threadIdx.x & 63) == 0) mx[threadIdx.x >> 6] = v;
+    __syncthreads();
+    v = max(max(mx[0], mx[1]), max(mx[2], mx[3]));
+    __syncthreads();
+    return v;
+}
+__device__ __forceinline__ uint32_t block_or(uint32_t v) {
+    __shared__ uint32_t ov[4];
+    for (int d = 32; d > 0; d >>= 1) v |= (uint32_t)__shfl_xor((int)v, d);
+    if ((threadIdx.x & 63) == 0) ov[threadIdx.x >> 6] = v;
+    __syncthreads();
+    v = ov[0] | ov[1] | ov[2] | ov[3];
+    __syncthreads();
+    return v;
+}
+
+// Where a string pack's dictionary (or, for a front-coded pack, the output itself) lives as a StringsStruct.
+__device__ __forceinline__ uint8_t* str_dict_ptr(const DevPack& P, const PackMeta& M, uint8_t* out, uint8_t* scratch) {
+    return M.kind == K_DELTA_STR ? out + P.out_off : scratch + P.s_dict;
+}
+__device__ __forceinline__ uint64_t str_dict_cap(const DevPack& P, const PackMeta& M) {
+    return M.kind == K_DELTA_STR ? (uint64_t)P.data_size : P.dict_cap;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_str_dict_scan: one workgroup per string pack.
+//   front-coded entries: len[i] = prefixLen[i] + suffixLen[i];  offsets = exclusive scan(len) -> StringsStruct index,
+//                        sufOff = exclusive scan(suffixLen); validates prefixLen[i] <= len[i-1] and the promised sizes.
+//   plain entries:       copies the StringsStruct out of the pack (PlainCodec.decodeStrings, PlainCodec.java:73-77) and
+//                        validates its offsets.
+// (DeltaCodec.decodeStrings sizes, DeltaCodec.java:355-388; StringsStruct.java:12-17)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_str_dict_scan(const DevPack* __restrict__ packs, const int* __restrict__ list,
+                                                       PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
+                                                       uint8_t* __restrict__ out, uint8_t* __restrict__ scratch) {
+    const int pi = list[blockIdx.x];
+    PackMeta& M = metas[pi];
+    if (M.status < 0 || (M.kind != K_DICT_STR && M.kind != K_DELTA_STR)) return;
+    const DevPack P = packs[pi];
+    const uint8_t* base = in + P.in_off;
+    const uint32_t ec = M.entry_count;
+    const int tid = threadIdx.x;
+    uint8_t* dict = str_dict_ptr(P, M, out, scratch);
+    const uint64_t cap = str_dict_cap(P, M);
+    uint32_t* doff = (uint32_t*)dict;
+    if ((uint64_t)4 * (ec + 1) > cap) { if (tid == 0) M.status = E_OVERFLOW; return; }
+
+    if (M.entries_plain) {
+        const uint8_t* src = base + M.entries_off;
+        const uint32_t total = ld32u(src + 4ull * ec);
+        const uint64_t bytes = 4ull * (ec + 1) + total;
+        if (bytes > cap) { if (tid == 0) M.status = E_OVERFLOW; return; }
+        uint32_t bad = 0, mx = 0;
+        for (uint32_t i = tid; i < ec; i += 256) {
+            uint32_t a = ld32u(src + 4ull * i), b = ld32u(src + 4ull * (i + 1));
+            if (a > b || b > total) bad = 1; else mx = max(mx, b - a);
+        }
+        if (ld32u(src) != 0) bad = 1;
+        bad = block_or(bad);
+        mx = block_max(mx);
+        if (bad) { if (tid == 0) M.status = E_CORRUPT; return; }
+        for (uint64_t i = tid; i < bytes; i += 256) dict[i] = src[i];
+        if (tid == 0) M.max_len = mx;
+        return;
+    }
+
+    const int32_t* pre = (const int32_t*)(scratch + P.s_lens);
+    const int32_t* suf = pre + lens_stride(P.obj_count);
+    uint32_t* sufoff = (uint32_t*)(suf + lens_stride(P.obj_count));
+    // validation pass: non-negative, prefix fits into the previous string, lengths bounded
+    uint32_t bad = 0, mx = 0;
+    for (uint32_t i = tid; i < ec; i += 256) {
+        const int32_t p = pre[i], s = suf[i];
+        const int64_t prevlen = i ? (int64_t)pre[i - 1] + suf[i - 1] : 0;
+        if (p < 0 || s < 0 || p > prevlen || (int64_t)p + s > 0x7fffffff) bad = 1;
+        else mx = max(mx, (uint32_t)(p + s));
+    }
+    bad = block_or(bad);
+    mx = block_max(mx);
+    if (bad) { if (tid == 0) M.status = E_CORRUPT; return; }
+    // the individual lengths are sane; the totals are checked against 64-bit sums below via saturating compare
+    uint32_t total_len = block_excl_scan(
+        ec, [&](uint32_t i) { return (uint32_t)(pre[i] + suf[i]); },
+        [&](uint32_t i, uint32_t ex, uint32_t) { doff[i] = ex; });
+    __syncthreads();
+    uint32_t total_suf = block_excl_scan(
+        ec, [&](uint32_t i) { return (uint32_t)suf[i]; }, [&](uint32_t i, uint32_t ex, uint32_t) { sufoff[i] = ex; });
+    // 32-bit wrap of the totals is impossible to hit without also exceeding `cap`, as long as every partial sum is
+    // checked: do it with a 64-bit reduction
+    uint64_t s64 = 0;
+    for (uint32_t i = tid; i < ec; i += 256) s64 += (uint64_t)(uint32_t)(pre[i] + suf[i]);
+    __shared__ unsigned long long tot64;
+    if (tid == 0) tot64 = 0;
+    __syncthreads();
+    atomicAdd(&tot64, (unsigned long long)s64);
+    __syncthreads();
+    if (tid == 0) {
+        if (tot64 + 4ull * (ec + 1) > cap) M.status = E_OVERFLOW;
+        else if (total_suf != M.sfx_len) M.status = E_CORRUPT;
+        else {
+            doff[ec] = total_len;
+            sufoff[ec] = total_suf;
+            M.max_len = mx;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_front_decode: expands a front-coded string list (string i = first prefixLen[i] bytes of string i-1 + its suffix,
+// DeltaCodec.java:368-383).  Column parallel: a wave owns 64 byte columns [64g, 64g+64); lane j keeps the current byte
+// of its column in a register while the wave steps through the strings in order -- the prefix of a string is exactly
+// what the registers already hold, only columns covered by the suffix load a new byte.  No dependency between
+// iterations goes through memory, so the loads pipeline.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_front_decode(const DevPack* __restrict__ packs, const int* __restrict__ list,
+                                                     const PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
+                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ scratch) {
+    const int pi = list[blockIdx.y];
+    const PackMeta& M = metas[pi];
+    if (M.status < 0 || (M.kind != K_DICT_STR && M.kind != K_DELTA_STR) || M.entries_plain) return;
+    const DevPack P = packs[pi];
+    const uint32_t ec = M.entry_count;
+    const uint32_t max_len = M.max_len;
+    const uint8_t* sfx = in + P.in_off + M.sfx_off;
+    uint8_t* dict = str_dict_ptr(P, M, out, scratch);
+    const uint32_t* doff = (const uint32_t*)dict;
+    uint8_t* body = dict + 4ull * (ec + 1);
+    const int32_t* pre = (const int32_t*)(scratch + P.s_lens);
+    const int32_t* suf = pre + lens_stride(P.obj_count);
+    const uint32_t* sufoff = (const uint32_t*)(suf + lens_stride(P.obj_count));
+    const int lane = threadIdx.x;
+    for (uint32_t col0 = blockIdx.x * 64; col0 < max_len; col0 += gridDim.x * 64) {
+        const uint32_t j = col0 + lane;
+        uint32_t cur = 0;
+        for (uint32_t i0 = 0; i0 < ec; i0 += 64) {
+            // each lane fetches the metadata of one string, then the wave steps through the 64 strings
+            const uint32_t ii = min(i0 + lane, ec - 1);
+            const uint32_t mp = (uint32_t)pre[ii], ms = (uint32_t)suf[ii], mo = doff[ii], mso = sufoff[ii];
+            const uint32_t cnt = min(64u, ec - i0);
+            for (uint32_t k = 0; k < cnt; k++) {
+                const uint32_t p = __shfl(mp, k), s = __shfl(ms, k);
+                const uint32_t len = p + s;
+                if (len <= col0) continue;  // uniform: nothing of this string lies in our columns
+                const uint32_t o = __shfl(mo, k), so = __shfl(mso, k);
+                if (j >= p && j < len) cur = sfx[so + (j - p)];
+                if (j < len) body[o + j] = (uint8_t)cur;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_str_rows: string dictionary packs, one wave per tile of kRleTile rows: expand ids, look up each row's dictionary
+// slice; writes the row length into the output index (slot i+1, scanned in place by k_row_scan) and the slice start
+// into scratch.  (DictStruct.decodeStrings, DictStruct.java:97-110.)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_str_rows(const DevPack* __restrict__ packs, const int* __restrict__ list,
+                                                  PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
+                                                  uint8_t* __restrict__ out, uint8_t* __restrict__ scratch) {
+    const int pi = list[blockIdx.y];
+    const PackMeta& M = metas[pi];
+    if (M.status < 0 || M.kind != K_DICT_STR) return;
+    const DevPack P = packs[pi];
+    const uint32_t n = (uint32_t)P.obj_count;
+    const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t tile_start = tile * kRleTile;
+    if (tile_start >= n) return;
+    const uint32_t tile_end = min(n, tile_start + (uint32_t)kRleTile);
+    const uint8_t* base = in + P.in_off;
+    const uint32_t* doff = (const uint32_t*)(scratch + P.s_dict);
+    uint32_t* rowlen = (uint32_t*)(out + P.out_off) + 1;
+    uint32_t* srcoff = (uint32_t*)(scratch + P.s_rows);
+    const uint32_t ec = M.entry_count;
+    const uint2 restart = ((const uint2*)(scratch + P.s_restart))[tile];
+    bool bad = false;
+    rle_tile_foreach(base, M, restart, tile_start, tile_end, [&](uint32_t i, uint32_t id) {
+        if (id >= ec) { bad = true; id = 0; }
+        const uint32_t a = doff[id], b = doff[id + 1];
+        rowlen[i] = b - a;
+        srcoff[i] = a;
+    });
+    if (bad) metas[pi].status = E_CORRUPT;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_row_scan: one workgroup per string dictionary pack: turns the row lengths in the output index into offsets
+// (offset[0] = 0, offset[i+1] = offset[i] + len[i]; StringsStruct.Builder, StringsStruct.java:120-158), checks that the
+// body fits the output.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_row_scan(const DevPack* __restrict__ packs, const int* __restrict__ list,
+                                                  PackMeta* __restrict__ metas, uint8_t* __restrict__ out) {
+    const int pi = list[blockIdx.x];
+    PackMeta& M = metas[pi];
+    if (M.status < 0 || M.kind != K_DICT_STR) return;
+    const DevPack P = packs[pi];
+    const uint32_t n = (uint32_t)P.obj_count;
+    uint32_t* off = (uint32_t*)(out + P.out_off);
+    if (4ull * (n + 1) > (uint64_t)P.data_size) { if (threadIdx.x == 0) M.status = E_OVERFLOW; return; }
+    const uint32_t body_cap = (uint32_t)P.data_size - 4u * (n + 1);
+    // Any row length is < 2^31 and validated dictionary slices are <= data_size, so a total beyond body_cap is detected
+    // from the 64-bit sum; the in-place scan itself may wrap harmlessly in that case because the copy is skipped.
+    uint64_t s64 = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) s64 += off[i + 1];
+    __shared__ unsigned long long tot64;
+    if (threadIdx.x == 0) tot64 = 0;
+    __syncthreads();
+    atomicAdd(&tot64, (unsigned long long)s64);
+    __syncthreads();
+    if (tot64 > body_cap) {  // the body must fit dpn.dataSize = index + body (DataPackCreator_VLT.java:185-205)
+        if (threadIdx.x == 0) M.status = E_OVERFLOW;
+        return;
+    }
+    block_excl_scan(
+        n, [&](uint32_t i) { return off[i + 1]; },
+        [&](uint32_t i, uint32_t ex, uint32_t v) { off[i + 1] = ex + v; });
+    if (threadIdx.x == 0) off[0] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_str_copy: string dictionary packs: body[offset[i] .. offset[i+1]) = dictBody[srcOff[i] ..].  One workgroup per tile of
+// kStrTileRows rows; the tile's offsets and source offsets are staged in LDS; each lane produces one aligned 4-byte
+// word of the output body per step (binary search of the word's first byte in the staged offsets, then a short walk for
+// words that straddle rows), so stores are fully coalesced however short the strings are.
+// (StringsStruct.Builder.addString copy, StringsStruct.java:120-131.)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_str_copy(const DevPack* __restrict__ packs, const int* __restrict__ list,
+                                                  const PackMeta* __restrict__ metas, uint8_t* __restrict__ out,
+                                                  const uint8_t* __restrict__ scratch) {
+    const int pi = list[blockIdx.y];
+    const PackMeta& M = metas[pi];
+    if (M.status < 0 || M.kind != K_DICT_STR) return;
+    const DevPack P = packs[pi];
+    const uint32_t n = (uint32_t)P.obj_count;
+    const uint32_t r0 = blockIdx.x * kStrTileRows;
+    if (r0 >= n) return;
+    const uint32_t rows = min((uint32_t)kStrTileRows, n - r0);
+    const uint32_t* off = (const uint32_t*)(out + P.out_off);
+    uint8_t* body = out + P.out_off + 4ull * (n + 1);
+    const uint32_t ec = M.entry_count;
+    const uint8_t* dbody = scratch + P.s_dict + 4ull * (ec + 1);
+    const uint32_t* srcoff = (const uint32_t*)(scratch + P.s_rows);
+
+    __shared__ uint32_t s_off[kStrTileRows + 1];
+    __shared__ uint32_t s_src[kStrTileRows];
+    const int tid = threadIdx.x;
+    for (uint32_t i = tid; i <= rows; i += 256) s_off[i] = off[r0 + i];
+    for (uint32_t i = tid; i < rows; i += 256) s_src[i] = srcoff[r0 + i];
+    __syncthreads();
+    const uint32_t b0 = s_off[0], b1 = s_off[rows];
+    if (b1 <= b0) return;
+    // body + b0 is arbitrary; work on words aligned in the absolute address space of the body
+    const uint32_t w0 = b0 & ~3u;
+    for (uint32_t wpos = w0 + 4 * tid; wpos < b1; wpos += 4 * 256) {
+        // first byte of this word that belongs to the tile
+        const uint32_t first = max(wpos, b0);
+        // binary search: largest r in [0, rows) with s_off[r] <= first
+        uint32_t lo = 0, hi = rows;  // invariant: s_off[lo] <= first < s_off[hi]
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_off[mid] <= first) lo = mid; else hi = mid;
+        }
+        uint32_t r = lo;
+        uint32_t rend = s_off[r + 1];
+        uint32_t delta = s_src[r] - s_off[r];  // source = dbody + pos + delta (mod 2^32)
+        uint32_t word = 0;
+        uint32_t mask = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t pos = wpos + k;
+            if (pos >= b0 && pos < b1) {
+                while (pos >= rend) { r++; rend = s_off[r + 1]; delta = s_src[r] - s_off[r]; }
+                word |= (uint32_t)dbody[pos + delta] << (8 * k);
+                mask |= 0xFFu << (8 * k);
+            }
+        }
+        if (mask == 0xFFFFFFFFu) *(uint32_t*)(body + wpos) = word;
+        else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (mask & (0xFFu << (8 * k))) body[wpos + k] = (uint8_t)(word >> (8 * k));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_dict_struct: materialises the uncompressed DictStruct of DICT_COMPRESS packs (PackCompressor_VLT.getDictStruct,
+// PackCompressor_VLT.java:172-186; layout DictStruct.java:14-55): entryCount | entries | 4n | ids.
+// grid.x = 1 + tiles/4: block 0 copies header + entries from the scratch dictionary, the others expand the ids.
+// The id region can be unaligned (string dictionaries have arbitrary byte size), so ids are stored bytewise then.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dict_struct(const DevPack* __restrict__ packs, const int* __restrict__ list,
+                                                     PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
+                                                     uint8_t* __restrict__ out, const uint8_t* __restrict__ scratch) {
+    const int pi = list[blockIdx.y];
+    const PackMeta& M = metas[pi];
+    if (M.status < 0 || (M.kind != K_DICT_NUM && M.kind != K_DICT_STR) || M.dict_struct_size == 0) return;
+    const DevPack P = packs[pi];
+    const uint32_t n = (uint32_t)P.obj_count;
+    const uint32_t ec = M.entry_count;
+    const uint8_t* dict = scratch + P.s_dict;
+    uint8_t* ds = out + P.ds_off;
+    uint32_t dict_size;
+    if (M.kind == K_DICT_NUM) dict_size = ec * (uint32_t)(P.width / 8);
+    else dict_size = 4 * (ec + 1) + ((const uint32_t*)dict)[ec];
+    if (4ull + dict_size + 4ull + 4ull * n != (uint64_t)M.dict_struct_size) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) metas[pi].status = E_CORRUPT;
+        return;
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) {
+            *(uint32_t*)ds = ec;
+            const uint32_t v = 4 * n;
+            uint8_t* p = ds + 4 + dict_size;
+            p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24);
+        }
+        // ds + 4 and dict are both 4-byte aligned
+        const uint32_t words = dict_size >> 2;
+        for (uint32_t i = threadIdx.x; i < words; i += 256) ((uint32_t*)(ds + 4))[i] = ((const uint32_t*)dict)[i];
+        for (uint32_t i = (words << 2) + threadIdx.x; i < dict_size; i += 256) ds[4 + i] = dict[i];
+        return;
+    }
+    const uint32_t tile = (blockIdx.x - 1) * 4 + (threadIdx.x >> 6);
+    const uint32_t tile_start = tile * kRleTile;
+    if (tile_start >= n) return;
+    const uint32_t tile_end = min(n, tile_start + (uint32_t)kRleTile);
+    uint8_t* ids = ds + 4 + dict_size + 4;
+    const bool aligned = (((uintptr_t)ids) & 3) == 0;
+    const uint2 restart = ((const uint2*)(scratch + P.s_restart))[tile];
+    rle_tile_foreach(in + P.in_off, M, restart, tile_start, tile_end, [&](uint32_t i, uint32_t id) {
+        if (aligned) ((uint32_t*)ids)[i] = id;
+        else {
+            uint8_t* p = ids + 4ull * i;
+            p[0] = (uint8_t)id; p[1] = (uint8_t)(id >> 8); p[2] = (uint8_t)(id >> 16); p[3] = (uint8_t)(id >> 24);
+        }
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Rows out of an already uncompressed DictStruct (PackCompressor_VLT.getDataFromDictStruct, PackCompressor_VLT.java:188-213;
+// DictStruct.decodeXxx, DictStruct.java:57-110).  The "pack" handed to these kernels is the DictStruct itself.
+//   k_ds_meta   fills the meta record so that the regular dictionary kernels can be reused (plain entries at offset 4)
+//   k_ds_rows   reads the ids straight from the DictStruct (they may be unaligned) and gathers numbers, or produces the
+//               row lengths / source offsets of strings for k_row_scan + k_str_copy
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_ds_meta(const DevPack* __restrict__ packs, const int* __restrict__ list, int count,
+                          PackMeta* __restrict__ metas, const uint8_t* __restrict__ in) {
+    const int li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= count) return;
+    const int pi = list[li];
+    const DevPack P = packs[pi];
+    const uint8_t* base = in + P.in_off;
+    const uint32_t psz = (uint32_t)P.pack_size, n = (uint32_t)P.obj_count;
+    PackMeta m;
+    m.status = P.pack_size; m.kind = P.width ? K_DICT_NUM : K_DICT_STR; m.entry_count = 0; m.id_bw = 0; m.ids_off = 0;
+    m.ids_len = 0; m.entries_off = 4; m.entries_plain = 1; m.sfx_off = 0; m.sfx_len = 0; m.dict_struct_size = psz; m.max_len = 0;
+    m.s[0].n = m.s[1].n = 0; m.s[0].in_off = m.s[1].in_off = 0; m.s[0].first = m.s[1].first = 0;
+    int32_t err = 0;
+    if (psz < 8 || n == 0 || n > 65536u) err = E_CORRUPT;
+    if (!err) {
+        const uint32_t ec = ld32u(base);
+        if (ec == 0 || ec > 65536u) err = E_CORRUPT;
+        else {
+            m.entry_count = ec;
+            uint64_t dict_size;
+            if (P.width) dict_size = (uint64_t)ec * (P.width / 8);
+            else if (4ull + 4ull * (ec + 1) > psz) { err = E_CORRUPT; dict_size = 0; }
+            else dict_size = 4ull * (ec + 1) + ld32u(base + 4 + 4ull * ec);
+            if (!err && 4 + dict_size + 4 + 4ull * n > psz) err = E_CORRUPT;
+            if (!err && dict_size > P.dict_cap) err = E_OVERFLOW;
+            if (!err && ld32u(base + 4 + dict_size) != 4 * n) err = E_CORRUPT;
+            m.ids_off = (uint32_t)(4 + dict_size + 4);
+        }
+    }
+    if (err) m.status = err;
+    metas[pi] = m;
+}
+
+template <int MODE>  // 0: 32-bit numbers, 1: 64-bit numbers, 2: strings
+__global__ __launch_bounds__(256) void k_ds_rows(const DevPack* __restrict__ packs, const int* __restrict__ list,
+                                                 PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
+                                                 uint8_t* __restrict__ out, uint8_t* __restrict__ scratch) {
+    const int pi = list[blockIdx.y];
+    const PackMeta& M = metas[pi];
+    if (M.status < 0) return;
+    const DevPack P = packs[pi];
+    const uint32_t n = (uint32_t)P.obj_count, ec = M.entry_count;
+    const uint8_t* ids = in + P.in_off + M.ids_off;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t id = ld32u(ids + 4ull * i);
+    bool bad = false;
+    if (id >= ec) { bad = true; id = 0; }
+    if constexpr (MODE == 0) {
+        ((uint32_t*)(out + P.out_off))[i] = ((const uint32_t*)(scratch + P.s_dict))[id];
+    } else if constexpr (MODE == 1) {
+        ((uint64_t*)(out + P.out_off))[i] = ((const uint64_t*)(scratch + P.s_dict))[id];
+    } else {
+        const uint32_t* doff = (const uint32_t*)(scratch + P.s_dict);
+        const uint32_t a = doff[id], b = doff[id + 1];
+        ((uint32_t*)(out + P.out_off))[i + 1] = b - a;
+        ((uint32_t*)(scratch + P.s_rows))[i] = a;
+    }
+    if (bad) metas[pi].status = E_CORRUPT;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_checksum: position-weighted checksum of every decoded pack (same formula as ixr_checksum on the host), so that
+// full-size outputs can be verified where they lie.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_checksum(const DevPack* __restrict__ packs, int count, const uint8_t* __restrict__ out,
+                                                  unsigned long long* __restrict__ sums) {
+    const int pi = blockIdx.x;
+    if (pi >= count) return;
+    const DevPack P = packs[pi];
+    const uint64_t bytes = (uint64_t)P.data_size;
+    const uint8_t* p = out + P.out_off;
+    const uint64_t words = bytes >> 3;
+    unsigned long long sum = 0;
+    for (uint64_t i = threadIdx.x; i < words; i += 256) {
+        const unsigned long long w = ((const unsigned long long*)p)[i];
+        sum += (w + 0x9E3779B97F4A7C15ull) * (2 * i + 1);
+    }
+    if (threadIdx.x == 0 && (bytes & 7)) {
+        unsigned long long w = 0;
+        for (uint32_t k = 0; k < (bytes & 7); k++) w |= (unsigned long long)p[8 * words + k] << (8 * k);
+        sum += (w + 0x9E3779B97F4A7C15ull) * (2 * words + 1);
+    }
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+    __shared__ unsigned long long part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[pi] = part[0] + part[1] + part[2] + part[3];
+}
+
+// ===============================================================================================================
+// launchers
+// ===============================================================================================================
+static inline unsigned cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }
+
+void launch_parse(const LaunchCtx& c, const int* list, int count) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_parse, dim3(cdiv((unsigned)count * 4, 256)), dim3(256), 0, c.stream, c.packs, list, count, c.metas,
+                       c.in, c.scratch);
+}
+void launch_delta(const LaunchCtx& c, const int* list, int count, int width, int streams) {
+    if (count <= 0) return;
+    if (width == 64)
+        hipLaunchKernelGGL(k_delta<uint64_t>, dim3(count, streams), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out,
+                           c.scratch);
+    else
+        hipLaunchKernelGGL(k_delta<uint32_t>, dim3(count, streams), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out,
+                           c.scratch);
+}
+void launch_dict_num(const LaunchCtx& c, const int* list, int count, int width) {
+    if (count <= 0) return;
+    const unsigned gx = IXR_PACK_TILES / 4;
+    if (width == 64)
+        hipLaunchKernelGGL(k_dict_num<uint64_t>, dim3(gx, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out,
+                           c.scratch);
+    else
+        hipLaunchKernelGGL(k_dict_num<uint32_t>, dim3(gx, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out,
+                           c.scratch);
+}
+void launch_copy_raw(const LaunchCtx& c, const int* list, int count) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_copy_raw, dim3(8, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out);
+}
+void launch_str_dict_scan(const LaunchCtx& c, const int* list, int count) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_str_dict_scan, dim3(count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+}
+void launch_front_decode(const LaunchCtx& c, const int* list, int count) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_front_decode, dim3(4, count), dim3(64), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+}
+void launch_str_rows(const LaunchCtx& c, const int* list, int count) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_str_rows, dim3(IXR_PACK_TILES / 4, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out,
+                       c.scratch);
+}
+void launch_row_scan(const LaunchCtx& c, const int* list, int count) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_row_scan, dim3(count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.out);
+}
+void launch_str_copy(const LaunchCtx& c, const int* list, int count) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_str_copy, dim3(IXR_PACK_MAX_ROWS_ / kStrTileRows, count), dim3(256), 0, c.stream, c.packs, list, c.metas,
+                       c.out, c.scratch);
+}
+void launch_ds_meta(const LaunchCtx& c, const int* list, int count) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_ds_meta, dim3(cdiv((unsigned)count, 64)), dim3(64), 0, c.stream, c.packs, list, count, c.metas, c.in);
+}
+void launch_ds_rows(const LaunchCtx& c, const int* list, int count, int mode) {
+    if (count <= 0) return;
+    const dim3 g(IXR_PACK_MAX_ROWS_ / 256, count), b(256);
+    if (mode == 0) hipLaunchKernelGGL(k_ds_rows<0>, g, b, 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+    else if (mode == 1) hipLaunchKernelGGL(k_ds_rows<1>, g, b, 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+    else hipLaunchKernelGGL(k_ds_rows<2>, g, b, 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+}
+void launch_checksum(const LaunchCtx& c, int count, unsigned long long* sums) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_checksum, dim3(count), dim3(256), 0, c.stream, c.packs, count, c.out, sums);
+}
+void launch_dict_struct(const LaunchCtx& c, const int* list, int count) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_dict_struct, dim3(1 + IXR_PACK_TILES / 4, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in,
+                       c.out, c.scratch);
+}
+
+}  // namespace ixr

@@ -1,0 +1,37 @@
+// ixr_launch.h -- host-callable launch wrappers of the kernels in ixr_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ixr_device.h"
+
+#define IXR_PACK_MAX_ROWS_ 65536
+#define IXR_PACK_TILES (IXR_PACK_MAX_ROWS_ / 1024)
+
+namespace ixr {
+
+struct LaunchCtx {
+    hipStream_t stream;
+    const DevPack* packs;  // device array, all packs of the plan
+    PackMeta* metas;       // device array, all packs of the plan
+    const uint8_t* in;     // input arena
+    uint8_t* out;          // output arena
+    uint8_t* scratch;      // scratch base of the current group
+};
+
+// `list` is a device array of `count` pack indices.
+void launch_parse(const LaunchCtx& c, const int* list, int count);
+void launch_delta(const LaunchCtx& c, const int* list, int count, int width, int streams);
+void launch_dict_num(const LaunchCtx& c, const int* list, int count, int width);
+void launch_copy_raw(const LaunchCtx& c, const int* list, int count);
+void launch_str_dict_scan(const LaunchCtx& c, const int* list, int count);
+void launch_front_decode(const LaunchCtx& c, const int* list, int count);
+void launch_str_rows(const LaunchCtx& c, const int* list, int count);
+void launch_row_scan(const LaunchCtx& c, const int* list, int count);
+void launch_str_copy(const LaunchCtx& c, const int* list, int count);
+void launch_ds_meta(const LaunchCtx& c, const int* list, int count);
+void launch_ds_rows(const LaunchCtx& c, const int* list, int count, int mode);  // 0: 32 bit, 1: 64 bit, 2: strings
+void launch_checksum(const LaunchCtx& c, int count, unsigned long long* sums);  // all packs of the plan
+void launch_dict_struct(const LaunchCtx& c, const int* list, int count);
+
+}  // namespace ixr

@@ -1,0 +1,305 @@
+"""GPU parity tests: the HIP decoder, called through the C ABI (libixrgpu.so), against the CPU oracle on the same inputs.
+
+Bar: bit-exact (integer / byte work; floats and doubles are moved as bit patterns, never computed on).
+The inputs restate the reference's own tests: DataPackTest literal inputs, DeltaCodecTest random walks,
+RLEPackingHybridCodecTest random runs, DictCodecTest cardinality sweeps over all five types, plus edge cases (tails < 8,
+every bit width, wrap-around, empty strings, maximum pack size, corrupted streams).
+"""
+import struct
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import pyref as R
+from gpu_util import Case, check_cases, run_batch
+from indexr_amd import lib as L
+from test_oracle import ALL_TYPES, DATAPACK_CASES, _column, _strings, rng
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_case(rows, data_type, encode_type=None, is_indexed=False, name=""):
+    """Encode with the oracle (choice of codec as the reference, or forced), expected output = oracle decode."""
+    n = len(rows)
+    data = O.rows_to_bytes(rows, data_type)
+    if encode_type is None:
+        pack, et = O.compress_pack(data, data_type, n, is_indexed)
+    else:
+        pack, et = O.compress_pack_as(data, data_type, n, encode_type), encode_type
+    dec, consumed = O.decompress_pack(pack, data_type, et, n, len(data))
+    assert consumed == len(pack) and (dec == data).all()
+    return Case(pack, data_type, et, n, len(data), dec, name or "type%d enc%d n%d" % (data_type, et, n))
+
+
+def test_device_is_gfx950():
+    assert L.lib.ixr_device_count() >= 1
+    assert L.lib.ixr_init(0) == 0, L.lib.ixr_last_error()
+
+
+def test_datapack_literal_inputs():
+    cases = []
+    for data_type, rows in DATAPACK_CASES:
+        for is_indexed in (False, True):
+            cases.append(oracle_case(rows, data_type, None, is_indexed))
+        for et in (O.DELTA, O.SIMPLE_DICT, O.DICT_COMPRESS, 0):
+            cases.append(oracle_case(rows, data_type, et))
+    check_cases(cases)
+
+
+def test_delta_ints_sizes_and_widths():
+    cases = []
+    i32 = np.iinfo(np.int32)
+    for n in [1, 2, 3, 4, 5, 7, 8, 9, 31, 32, 33, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 4097, 65535, 65536]:
+        r = rng(n)
+        walk = np.cumsum(r.integers(-100000, 10000000, size=n)).astype(np.int64)
+        cases.append(oracle_case((walk & 0xFFFFFFFF).astype(np.uint32).view("<i4"), O.INT, O.DELTA))
+    cases.append(oracle_case(np.array([i32.min, i32.max] * 500, dtype="<i4"), O.INT, O.DELTA, name="wrap"))
+    cases.append(oracle_case(np.zeros(3000, dtype="<i4"), O.INT, O.DELTA, name="bw0"))
+    cases.append(oracle_case(rng(5).integers(i32.min, i32.max, size=65536, dtype=np.int64).astype("<i4"), O.INT, O.DELTA, name="rand32"))
+    vals = [0]
+    for bw in range(33):
+        for k in range(32):
+            vals.append((vals[-1] + ((1 << bw) - 1 if k == 3 and bw else 0)) & 0xFFFFFFFF)
+    cases.append(oracle_case(np.array(vals, dtype=np.uint32).view("<i4"), O.INT, O.DELTA, name="every width"))
+    f = np.array([1, 2, 3, 5, 6, 7, 8, 9, 1111.4666, 333, 0, np.nan, -0.0, np.inf, -np.inf] * 300, dtype="<f4")
+    cases.append(oracle_case(f, O.FLOAT, O.DELTA, name="float bits"))
+    check_cases(cases)
+
+
+def test_delta_longs_sizes_and_widths():
+    cases = []
+    i64 = np.iinfo(np.int64)
+    for n in [1, 2, 5, 31, 32, 33, 127, 128, 129, 1000, 1024, 1025, 65535, 65536]:
+        r = rng(1000 + n)
+        cases.append(oracle_case(np.cumsum(r.integers(-10**12, 10**15, size=n)).astype("<i8"), O.LONG, O.DELTA))
+    cases.append(oracle_case(np.array([i64.min, i64.max] * 300, dtype="<i8"), O.LONG, O.DELTA, name="wrap"))
+    cases.append(oracle_case(rng(6).integers(i64.min, i64.max, size=65536, dtype=np.int64).astype("<i8"), O.LONG, O.DELTA, name="rand64"))
+    vals = [0]
+    for bw in range(65):
+        for k in range(32):
+            vals.append((vals[-1] + ((1 << bw) - 1 if k == 5 and bw else 0)) & 0xFFFFFFFFFFFFFFFF)
+    cases.append(oracle_case(np.array(vals, dtype=np.uint64).view("<i8"), O.LONG, O.DELTA, name="every width"))
+    d = np.array([1, 2, 3, 5, 4.9e-324, 7, 1.7976931348623157e308, 9, 1111, -333.4444444, 0, np.nan, -0.0] * 200, dtype="<f8")
+    cases.append(oracle_case(d, O.DOUBLE, O.DELTA, name="double bits"))
+    check_cases(cases)
+
+
+@pytest.mark.parametrize("data_type", ALL_TYPES)
+def test_dict_codecs_cardinality_sweep(data_type):
+    # DictCodecTest.java:41-274: all types x {SimpleDict, DictCompress}, cardinality sweep, 65536 values
+    cases = []
+    for card in [1, 2, 3, 10, 63, 64, 65, 255, 256, 257, 1010, 5010, 20010, 65536]:
+        r = rng(card * 10 + data_type)
+        n = 65536 if card in (1, 1010, 65536) else int(r.integers(1000, 30000))
+        rows = _column(r, data_type, n, card)
+        for et in (O.DICT_COMPRESS, O.SIMPLE_DICT):
+            cases.append(oracle_case(rows, data_type, et, name="type%d enc%d card%d n%d" % (data_type, et, card, n)))
+    check_cases(cases)
+
+
+def test_rle_runs():
+    # RLEPackingHybridCodecTest.java:27-69 : random runs of length 0..15, plus long runs crossing tiles
+    cases = []
+    for seed, card in enumerate([1, 2, 7, 300, 40000]):
+        r = rng(seed)
+        vals = []
+        while len(vals) < 65536:
+            vals += [int(r.integers(0, card))] * int(r.integers(0, 16))
+        for n in [1, 7, 8, 9, 1023, 1024, 1025, 65536]:
+            cases.append(oracle_case(np.array(vals[:n], dtype="<i4") * 3 - 7, O.INT, O.DICT_COMPRESS, name="runs card%d n%d" % (card, n)))
+    r = rng(99)
+    vals = []
+    while len(vals) < 65536:
+        vals += [int(r.integers(0, 5))] * int(r.integers(1, 5000))
+    cases.append(oracle_case(np.array(vals[:65536], dtype="<i8") * 1000003, O.LONG, O.DICT_COMPRESS, name="long runs"))
+    cases.append(oracle_case(np.full(65536, 7.25, dtype="<f8"), O.DOUBLE, O.DICT_COMPRESS, name="one value"))
+    check_cases(cases)
+
+
+def test_strings():
+    cases = []
+    r = rng(1)
+    for n in [1, 2, 63, 64, 65, 1000, 65536]:
+        cases.append(oracle_case(_strings(r, n), O.STRING, O.DICT_COMPRESS, name="str dict n%d" % n))
+        cases.append(oracle_case(_strings(r, n), O.STRING, O.SIMPLE_DICT, name="str simple n%d" % n))
+        cases.append(oracle_case(_strings(r, n), O.STRING, O.DELTA, name="str delta n%d" % n))
+    cases.append(oracle_case([b""] * 5000, O.STRING, name="all empty"))
+    cases.append(oracle_case([b"x" * 300, b"x" * 299 + b"y", b"", b"x" * 65535, b"abc"] * 11, O.STRING, O.DICT_COMPRESS, name="long strings"))
+    cases.append(oracle_case([b"x" * 70000][0:0] + [bytes([i % 251]) * (i % 400) for i in range(3000)], O.STRING, O.DICT_COMPRESS, name="ragged"))
+    cases.append(oracle_case([bytes([i % 251]) * (i % 400) for i in range(3000)], O.STRING, O.DELTA, name="ragged delta"))
+    uniq = [b"%08d" % int(v) for v in rng(3).integers(0, 10**8, size=65536)]
+    cases.append(oracle_case(uniq, O.STRING, O.DICT_COMPRESS, name="unique strings"))
+    cases.append(oracle_case(sorted(uniq), O.STRING, O.DELTA, name="sorted unique delta"))
+    check_cases(cases)
+
+
+def test_synthetic_columns_all_kinds_with_small_scratch_budget():
+    reqs = []
+    for kind in range(13):
+        for pack_id, rows in ((0, 65536), (1, 65536), (2, 16960)):
+            reqs.append((kind, pack_id, rows, 0))
+    descs, arena, out_bytes, sums = L.synth_build(reqs, 0xC0FFEE, threads=8)
+    for budget in (0, 24 << 20):  # second run forces several scratch groups
+        plan = L.Plan(0, descs, budget)
+        d_in = L.DeviceBuffer(0, len(arena))
+        d_out = L.DeviceBuffer(0, out_bytes + 16)
+        d_in.upload(arena)
+        plan.run(d_in.ptr, len(arena), d_out.ptr, out_bytes + 16)
+        status, bad = plan.status()
+        assert bad == 0, status
+        got = plan.checksums(d_out.ptr, out_bytes + 16)
+        assert (got == sums).all()
+        host = d_out.download()
+        for (kind, pack_id, rows, _), d in zip(reqs, descs):
+            data = L.synth_column(kind, 0xC0FFEE, pack_id, rows)
+            assert host[d.out_off:d.out_off + d.data_size].tobytes() == data.tobytes(), (L.COL_NAMES[kind], pack_id)
+            dec, consumed = O.decompress_pack(arena[d.in_off:d.in_off + d.pack_size], d.data_type, d.encode_type, rows, d.data_size)
+            assert consumed == d.pack_size and dec.tobytes() == data.tobytes()
+        plan.destroy(); d_in.free(); d_out.free()
+
+
+def test_single_pack_entry_points():
+    r = rng(11)
+    for data_type in ALL_TYPES:
+        rows = _column(r, data_type, 5000, 300)
+        data = O.rows_to_bytes(rows, data_type)
+        pack, et = O.compress_pack(data, data_type, 5000, True)
+        assert et == O.DICT_COMPRESS
+        out, consumed = L.decode_pack(pack, data_type, et, 5000, len(data))
+        assert consumed == len(pack), L.lib.ixr_last_error()
+        assert out.tobytes() == data.tobytes()
+        # getDictStruct == oracle's DictStruct, then getDataFromDictStruct == rows
+        ds_o, c_o = O.get_dict_struct(pack, data_type, 5000)
+        ds_g, c_g = L.get_dict_struct(pack, data_type, 5000)
+        assert c_g == c_o == len(pack), L.lib.ixr_last_error()
+        assert ds_g.tobytes() == ds_o.tobytes()
+        rows_g, w = L.get_data_from_dict_struct(ds_g, data_type, 5000, len(data))
+        assert w == len(data), L.lib.ixr_last_error()
+        assert rows_g.tobytes() == data.tobytes()
+    # valCount == 0 => 0 bytes consumed (every reference codec: `if (valCount == 0) return 0`)
+    out, consumed = L.decode_pack(np.zeros(4, np.uint8), L.INT, L.ENC_DELTA, 0, 0)
+    assert consumed == 0
+    # illegal encode type
+    out, consumed = L.decode_pack(np.zeros(64, np.uint8), L.INT, 3, 10, 40)
+    assert consumed == L.ERR_ILLEGAL_ENCODE_TYPE
+
+
+def test_dict_structs_batch():
+    r = rng(12)
+    cases = []
+    for data_type in ALL_TYPES:
+        for card, n in ((1, 100), (40, 3000), (70, 65536), (3000, 20000)):
+            cases.append(oracle_case(_column(r, data_type, n, card), data_type, O.DICT_COMPRESS))
+    cases.append(oracle_case(np.arange(1000, dtype="<i4"), O.INT, O.DELTA))  # skipped by the DictStruct run
+    from gpu_util import build_arena, align16
+    descs, arena, _ = build_arena(cases)
+    ds_off, off = [], 0
+    for c in cases:
+        ds_off.append(off)
+        off += align16(8 + c.data_size + 4 * c.n)
+    plan = L.Plan(0, descs)
+    d_in = L.DeviceBuffer(0, len(arena)); d_out = L.DeviceBuffer(0, off + 16)
+    d_in.upload(arena)
+    plan.run_dict_structs(d_in.ptr, len(arena), d_out.ptr, off + 16, ds_off)
+    status, _ = plan.status()
+    host = d_out.download()
+    for c, o, st in zip(cases, ds_off, status):
+        assert st == len(c.pack)
+        if c.encode_type != O.DICT_COMPRESS:
+            continue
+        ds_o, c_o = O.get_dict_struct(c.pack, c.data_type, c.n)
+        assert c_o == len(c.pack)
+        assert host[o:o + len(ds_o)].tobytes() == ds_o.tobytes(), c.name
+    plan.destroy(); d_in.free(); d_out.free()
+
+
+def _corrupt_variants(case, r):
+    out = []
+    p = case.pack
+    # truncated pack
+    if len(p) > 8:
+        out.append(Case(p[:len(p) - 3], case.data_type, case.encode_type, case.n, case.data_size, None, case.name + " truncated"))
+    # a few random byte flips in the framing area; outcome must match the oracle: same bytes, or both fail
+    for k in range(6):
+        q = p.copy()
+        pos = int(r.integers(0, min(len(q), 64)))
+        q[pos] ^= 1 << int(r.integers(0, 8))
+        dec, consumed = O.decompress_pack(q, case.data_type, case.encode_type, case.n, case.data_size)
+        ok = consumed == len(q)
+        out.append(Case(q, case.data_type, case.encode_type, case.n, case.data_size, dec if ok else None, case.name + " flip%d@%d" % (k, pos)))
+    return out
+
+
+def test_corrupted_packs_fail_cleanly():
+    """Errors instead of faults. For every mutated pack the GPU must either report an error (when the oracle does) or
+    produce the oracle's bytes.  The GPU validates more strictly than the reference in two documented places
+    (stream length words must match the walked length; dictionary ids must be < entryCount), so a mutation the oracle
+    happens to accept may still be rejected by the GPU -- that is allowed, the converse is not."""
+    r = rng(77)
+    base = []
+    for data_type in ALL_TYPES:
+        base.append(oracle_case(_column(r, data_type, 3000, 100), data_type, O.DICT_COMPRESS))
+        base.append(oracle_case(_column(r, data_type, 3000, 100), data_type, O.DELTA))
+        base.append(oracle_case(_column(r, data_type, 3000, 100), data_type, O.SIMPLE_DICT))
+    cases = []
+    for c in base:
+        cases += _corrupt_variants(c, r)
+    outs, status, plan = run_batch(cases)
+    plan.destroy()
+    for c, out, st in zip(cases, outs, status):
+        if c.expect is None:
+            assert st != len(c.pack) or st < 0, c.name
+            assert st < 0 or st != len(c.pack), c.name
+        elif st == len(c.pack):
+            assert out.tobytes() == c.expect.tobytes(), c.name
+        else:
+            assert st < 0, c.name
+    # ids beyond the dictionary (bw allows 0..3, entryCount 3, id 3 used)
+    entries = struct.pack("<3i", 5, 6, 7)
+    ids = [0, 1, 2, 3, 1]
+    ds_size = 4 + 12 + 4 + 20
+    pack = struct.pack("<iiB", ds_size, 3, 0) + entries + R.rle_encode(ids, 2)
+    outs, status, plan = run_batch([Case(np.frombuffer(pack, np.uint8), L.INT, L.ENC_DICT_COMPRESS, 5, 20, None, "bad id")])
+    plan.destroy()
+    assert status[0] == L.ERR_DATA_CORRUPTED
+
+
+def test_bad_arguments():
+    d = L.PackDesc(8, 0, 10, 40, 10, L.ENC_DELTA, L.INT, 0)  # misaligned in_off
+    with pytest.raises(L.IxrError):
+        L.Plan(0, [d])
+    d = L.PackDesc(0, 0, 10, 40, 70000, L.ENC_DELTA, L.INT, 0)  # too many rows
+    with pytest.raises(L.IxrError):
+        L.Plan(0, [d])
+    good = L.PackDesc(0, 0, 100, 400, 100, L.ENC_DELTA, L.INT, 0)
+    plan = L.Plan(0, [good])
+    buf = L.DeviceBuffer(0, 1024)
+    with pytest.raises(L.IxrError):
+        plan.run(buf.ptr, 100, buf.ptr, 1024)  # arena smaller than pack + slack
+    plan.destroy(); buf.free()
+
+
+def test_config1_one_million_row_segment():
+    """BASELINE config 1: 1 000 000 rows = 15 full packs + 16 960 rows, columns {INT, BIGINT, DOUBLE, VARCHAR}; every decoded
+    pack compared byte for byte with the CPU reader (oracle)."""
+    kinds = [L.COL_I_CAT, L.COL_L_TS, L.COL_D_CARD, L.COL_S_URL]
+    reqs = []
+    for kind in kinds:
+        for p in range(16):
+            reqs.append((kind, p, 65536 if p < 15 else 1000000 - 15 * 65536, 0))
+    descs, arena, out_bytes, sums = L.synth_build(reqs, 0xC0FFEE, threads=8)
+    plan = L.Plan(0, descs)
+    d_in = L.DeviceBuffer(0, len(arena)); d_out = L.DeviceBuffer(0, out_bytes + 16)
+    d_in.upload(arena)
+    plan.run(d_in.ptr, len(arena), d_out.ptr, out_bytes + 16)
+    status, bad = plan.status()
+    assert bad == 0
+    assert plan.total_rows == 4 * 1000000
+    host = d_out.download()
+    for d in descs:
+        dec, consumed = O.decompress_pack(arena[d.in_off:d.in_off + d.pack_size], d.data_type, d.encode_type, d.obj_count, d.data_size)
+        assert consumed == d.pack_size
+        assert host[d.out_off:d.out_off + d.data_size].tobytes() == dec.tobytes()
+    assert (plan.checksums(d_out.ptr, out_bytes + 16) == sums).all()
+    plan.destroy(); d_in.free(); d_out.free()
