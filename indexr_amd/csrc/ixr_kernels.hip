@@ -657,6 +657,12 @@ __global__ __launch_bounds__(256) void k_str_dict_scan(const DevPack* __restrict
             M.max_len = mx;
         }
     }
+    if (M.kind == K_DELTA_STR && tot64 + 4ull * (ec + 1) <= cap) {
+        // front-coded pack decoded straight into the output: zero the unused tail (the reference's buffer is zero-filled)
+        uint8_t* tail = dict + 4ull * (ec + 1) + tot64;
+        const uint64_t rest = cap - (4ull * (ec + 1) + tot64);
+        for (uint64_t i = tid; i < rest; i += 256) tail[i] = 0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -768,6 +774,10 @@ __global__ __launch_bounds__(256) void k_row_scan(const DevPack* __restrict__ pa
         n, [&](uint32_t i) { return off[i + 1]; },
         [&](uint32_t i, uint32_t ex, uint32_t v) { off[i + 1] = ex + v; });
     if (threadIdx.x == 0) off[0] = 0;
+    // A body shorter than dpn.dataSize promises leaves a tail: the reference decodes into a zero-filled direct buffer
+    // (PackCompressor_VLT.java:133, ByteBufferUtil.java:31-36), so the tail reads as zeros.
+    uint8_t* tail = out + P.out_off + 4ull * (n + 1) + tot64;
+    for (uint64_t i = threadIdx.x; i < body_cap - tot64; i += 256) tail[i] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -12,9 +12,11 @@ def pytest_configure(config):
 
 
 def _has_gpu():
+    # Ask the library itself (HIP runtime of /opt/rocm).  torch is deliberately not imported here: it bundles its own copy
+    # of the HIP runtime, and a process must not initialise two of them.
     try:
-        import torch
-        return torch.cuda.is_available()
+        from indexr_amd import lib as L
+        return L.lib.ixr_device_count() > 0
     except Exception:
         return False
 

@@ -303,3 +303,17 @@ def test_config1_one_million_row_segment():
         assert host[d.out_off:d.out_off + d.data_size].tobytes() == dec.tobytes()
     assert (plan.checksums(d_out.ptr, out_bytes + 16) == sums).all()
     plan.destroy(); d_in.free(); d_out.free()
+
+
+def test_coexists_with_torch_when_torch_is_imported_first():
+    """bench.py needs torch.distributed for N > 1.  torch bundles its own libamdhip64 (same soname): importing torch first
+    makes libixrgpu bind to that copy, so one process holds one HIP runtime.  Run in a child process to keep this test
+    process on the system runtime."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import torch; assert torch.cuda.is_available(); torch.zeros(4, device='cuda').sum().item(); "
+            "import __graft_entry__ as g; g.smoke()")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
