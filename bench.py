@@ -1,0 +1,325 @@
+#!/usr/bin/env python3
+"""bench.py -- device-resident IndexR VLT pack decode on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (config.workload): BASELINE.json's mixed-type table -- columns INT (1000 categories), LONG (ms timestamps),
+FLOAT (k/10, 10 000 values), DOUBLE (k/10, 50 000 values), VARCHAR (Zipf over 50 000 URLs) -- `--rows` rows per GPU
+(default 1 000 000 000 = 15 259 packs per column), generated pack by pack from (seed, column, pack id) and compressed
+with the library's host encoder (same codec choice as the reference's writer).  With N GPUs every rank decodes its own
+`--rows`-row range of pack ids of an N x rows table (packs are independent; no data-path collective), so per-GPU work is
+fixed: "scaling": "weak".
+
+A step = one ixr_plan_run over the whole table: compressed packs are already in HBM, decoded packs stay in HBM.
+Reported: decoded GB/s (sum of dpn.dataSize / time) over all ranks, rows/s, per-kernel device times from HIP events on the
+launch stream, the roofline of the dominant kernel and of the whole job, and the CPU oracle timed on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy reaches
+
+WORKLOADS = {
+    # name: (description, column kinds)
+    "mixed": ("mixed-type table: INT i_cat, LONG l_ts, FLOAT f_card, DOUBLE d_card, VARCHAR s_url", [2, 4, 7, 8, 10]),
+    "numeric": ("numeric-only: INT i_seq/i_rand/i_cat/i_runs, LONG l_ts/l_card/l_rand", [0, 1, 2, 3, 4, 5, 6]),
+    "varchar": ("varchar-heavy: s_cat, s_url, s_uniq, s_empty", [9, 10, 11, 12]),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU")
+    ap.add_argument("--workload", default="mixed", choices=sorted(WORKLOADS))
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xC0FFEE)
+    ap.add_argument("--threads", type=int, default=0, help="host threads for input synthesis / CPU baseline")
+    ap.add_argument("--scratch-gib", type=float, default=8.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU time of each cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--with-copies", action="store_true", help="also time H2D + decode + D2H from/to pinned host memory on a sample")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        # torch first: libixrgpu then binds to the HIP runtime torch bundles (same soname), one runtime per process.
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    import numpy as np
+
+    from indexr_amd import lib as L
+
+    device = local_rank if world > 1 else 0
+    rc = L.lib.ixr_init(device)
+    if rc != 0:
+        raise SystemExit("ixr_init(%d) failed: %s" % (device, L.lib.ixr_last_error().decode()))
+    threads = args.threads or int(os.environ.get("IXR_BENCH_THREADS", "0")) or max(1, min(16, int(os.environ.get("OMP_NUM_THREADS", "16"))))
+    if threads == 1 and not args.threads:
+        threads = 16  # torchrun exports OMP_NUM_THREADS=1 when it is unset
+    desc_text, kinds = WORKLOADS[args.workload]
+    rows = args.rows
+    n_packs = (rows + 65535) >> 16  # DataPack.rowCountToPackCount (DataPack.java:773-803)
+    last_rows = rows - (n_packs - 1) * 65536
+    first_pack = rank * n_packs  # this rank's contiguous range of pack ids (SegmentAssigner-style contiguous split)
+
+    def log(msg):
+        if rank == 0:
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+
+    # ------------------------------------------------------------------ build the compressed table, chunk by chunk
+    t0 = time.time()
+    chunk_packs = 1024
+    host_chunks, all_descs, all_sums = [], [], []
+    in_off = out_off = 0
+    sample_for_cpu = None
+    for c0 in range(0, n_packs, chunk_packs):
+        c1 = min(n_packs, c0 + chunk_packs)
+        reqs = []
+        for p in range(c0, c1):
+            r = last_rows if p == n_packs - 1 else 65536
+            for k in kinds:
+                reqs.append((k, first_pack + p, r, 0))
+        descs, arena, chunk_out, sums = L.synth_build(reqs, args.seed, threads=threads)
+        body = len(arena) - L.IN_SLACK
+        for d in descs:
+            all_descs.append(L.PackDesc(d.in_off + in_off, d.out_off + out_off, d.pack_size, d.data_size, d.obj_count,
+                                        d.encode_type, d.data_type, 0))
+        all_sums.append(sums)
+        if sample_for_cpu is None:
+            sample_for_cpu = (list(descs), arena)
+        host_chunks.append((in_off, arena[:body]))
+        in_off += body
+        out_off += chunk_out
+        if (c0 // chunk_packs) % 4 == 0:
+            log("built %d / %d packs per column (%.0f s)" % (c1, n_packs, time.time() - t0))
+    in_bytes = in_off + L.IN_SLACK
+    out_bytes = out_off + 16
+    sums = np.concatenate(all_sums)
+    log("input built in %.1f s with %d threads: %d packs, %.2f GB compressed -> %.2f GB decoded"
+        % (time.time() - t0, threads, len(all_descs), in_off / 1e9, out_off / 1e9))
+
+    # ------------------------------------------------------------------ move to HBM, plan
+    d_in = L.DeviceBuffer(device, in_bytes)
+    d_out = L.DeviceBuffer(device, out_bytes)
+    t1 = time.time()
+    for off, chunk in host_chunks:
+        d_in.upload(chunk, off)
+    d_in.upload(np.zeros(L.IN_SLACK, dtype=np.uint8), in_off)
+    h2d_s = time.time() - t1
+    host_chunks = None
+    plan = L.Plan(device, all_descs, int(args.scratch_gib * (1 << 30)))
+    log("H2D %.2f GB in %.2f s (pageable); plan: scratch %.2f GB" % (in_bytes / 1e9, h2d_s, plan.scratch_bytes / 1e9))
+
+    def sync():
+        if L.lib.ixr_dev_synchronize(device) != 0:
+            raise SystemExit("device sync failed: " + L.lib.ixr_last_error().decode())
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    # ------------------------------------------------------------------ warm-up, then the timed region
+    for _ in range(args.warmup):
+        plan.run(d_in.ptr, in_bytes, d_out.ptr, out_bytes)
+    sync()
+    status, bad = plan.status()
+    if bad:
+        raise SystemExit("decode reported %d bad packs during warm-up (first statuses: %s)" % (bad, status[status != np.array([d.pack_size for d in all_descs])][:8]))
+    plan.set_profiling(True)
+    barrier()
+    sync()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        plan.run(d_in.ptr, in_bytes, d_out.ptr, out_bytes)
+    sync()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    plan.set_profiling(False)
+    status, bad = plan.status()  # also collects the per-kernel event times of the timed region
+    ktimes = plan.kernel_times()
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # the optional gather of decoded row counts: 3 counters per rank over RCCL, nothing on the data path
+        cnt = torch.tensor([plan.total_rows, plan.total_out, plan.total_in, bad], dtype=torch.int64, device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        tot_rows, tot_out, tot_in, bad_all = [int(v) for v in cnt.tolist()]
+    else:
+        tot_rows, tot_out, tot_in, bad_all = plan.total_rows, plan.total_out, plan.total_in, bad
+    if bad_all:
+        raise SystemExit("decode reported %d bad packs" % bad_all)
+
+    # ------------------------------------------------------------------ verification of the full-size output in place
+    verified = None
+    if not args.no_verify:
+        got = plan.checksums(d_out.ptr, out_bytes)
+        verified = bool((got == sums).all())
+        if not verified:
+            raise SystemExit("checksum mismatch on %d of %d packs" % (int((got != sums).sum()), len(sums)))
+
+    ms_per_step = elapsed / args.steps * 1e3
+    decoded_gbs = tot_out * args.steps / elapsed / 1e9
+    rows_per_s = tot_rows * args.steps / elapsed
+
+    # ------------------------------------------------------------------ roofline: dominant kernel + whole job
+    roofline = None
+    kernels = []
+    if ktimes:
+        tot_ms = sum(k[1] for k in ktimes)
+        for name, ms, launches, alg in sorted(ktimes, key=lambda k: -k[1]):
+            avg_ms = ms / max(launches, 1)
+            # alg = algorithmic bytes of one pass over the table; launches = launches over all steps of the timed region
+            gbs = alg * args.steps / (ms / 1e3) / 1e9 if ms > 0 else 0.0
+            kernels.append({"name": name, "ms_total": round(ms, 3), "launches": launches, "avg_ms": round(avg_ms, 4),
+                            "alg_bytes_per_step": alg, "alg_GBps": round(gbs, 1), "share": round(ms / tot_ms, 4)})
+        dom = kernels[0]
+        per_launch = dom["alg_bytes_per_step"] * args.steps / max(dom["launches"], 1)
+        achieved = per_launch / (dom["avg_ms"] / 1e3) / 1e9 if dom["avg_ms"] > 0 else 0.0
+        whole = (plan.total_in + plan.total_out) * args.steps / elapsed / 1e9
+        roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "alg_bytes_per_launch": int(per_launch), "avg_launch_ms": dom["avg_ms"],
+                    "whole_job": {"achieved": round(whole, 1), "frac": round(whole / HBM_PEAK_GBS, 4),
+                                  "alg_bytes_per_step": plan.total_in + plan.total_out,
+                                  "device_ms_per_step": round(tot_ms / args.steps, 3)}}
+
+    # ------------------------------------------------------------------ optional: rate including the PCIe copies
+    with_copies = None
+    if args.with_copies and rank == 0:
+        with_copies = time_with_copies(L, np, device, sample_for_cpu, args.scratch_gib)
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, bounded sample)
+    cpu_baseline = None
+    if rank == 0 and args.cpu_seconds > 0:
+        cpu_baseline = time_cpu_oracle(np, sample_for_cpu, threads, args.cpu_seconds, log)
+
+    if rank == 0:
+        out = {
+            "metric": "device-resident pack decode GB/s (decoded bytes)",
+            "value": round(decoded_gbs, 2),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8/u32/u64 (integer and byte moves; float/double handled as bit patterns)",
+            "data": "synthetic (deterministic per (seed, column, pack id); compressed by the library's host encoder)",
+            "config": {"workload": "%s, %d rows per GPU (%d packs x %d columns per GPU)" % (desc_text, rows, n_packs, len(kinds)),
+                       "rows_per_gpu": rows, "packs_per_gpu": len(all_descs), "parallelism": "packs sharded by pack id over %d GPU(s), no collective" % world,
+                       "compressed_GB_per_gpu": round(plan.total_in / 1e9, 3), "decoded_GB_per_gpu": round(plan.total_out / 1e9, 3)},
+            "rows_per_s": round(rows_per_s, 1),
+            "compression_ratio": round(plan.total_in / plan.total_out, 4),
+            "verified_bit_exact": verified,
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "kernels": kernels,
+        }
+        if with_copies:
+            out["with_copies"] = with_copies
+        print(json.dumps(out), flush=True)
+    plan.destroy()
+    d_in.free()
+    d_out.free()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def time_cpu_oracle(np, sample, threads, target_s, log):
+    """The CPU restatement of the reference decode (oracle/), timed on rank 0's first packs: one leg with 1 thread, one
+    with `threads` threads (one pack per task).  The reference itself is Java and cannot run in this image."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    descs, arena = sample
+    n = len(descs)
+    arr = (O.PackDesc * n)()
+    out_bytes = 0
+    for i, d in enumerate(descs):
+        arr[i] = O.PackDesc(d.in_off, d.out_off, d.pack_size, d.data_size, d.obj_count, d.encode_type, d.data_type, 0)
+        out_bytes = max(out_bytes, d.out_off + d.data_size)
+    out = np.zeros(out_bytes + 16, dtype=np.uint8)
+    in_p = arena.ctypes.data_as(C.POINTER(C.c_uint8))
+    out_p = out.ctypes.data_as(C.POINTER(C.c_uint8))
+
+    def leg(nthreads):
+        # calibrate on a few packs, then size the sample for ~target_s of work
+        k = min(n, 40)
+        t = time.perf_counter()
+        bad = O.lib.ixo_decode_batch(arr, k, in_p, out_p, nthreads)
+        dt = max(time.perf_counter() - t, 1e-4)
+        assert bad == 0
+        want = max(k, k * target_s / dt)  # packs worth ~target_s of work
+        m = int(min(n, want))
+        reps = max(1, int(round(want / m)))  # the sample is one chunk of the table; repeat it when it is too short
+        t = time.perf_counter()
+        for _ in range(reps):
+            bad = O.lib.ixo_decode_batch(arr, m, in_p, out_p, nthreads)
+            assert bad == 0
+        dt = time.perf_counter() - t
+        dec = sum(descs[i].data_size for i in range(m)) * reps
+        rows = sum(descs[i].obj_count for i in range(m)) * reps
+        return m * reps, dt, dec / dt / 1e9, rows / dt
+
+    m1, dt1, gbs1, rps1 = leg(1)
+    log("cpu oracle, 1 thread: %d packs in %.1f s = %.3f GB/s decoded" % (m1, dt1, gbs1))
+    mt, dtt, gbst, rpst = leg(threads)
+    log("cpu oracle, %d threads: %d packs in %.1f s = %.3f GB/s decoded" % (threads, mt, dtt, gbst))
+    return {"value": round(gbst, 3), "unit": "GB/s", "cores": threads, "kind": "port",
+            "sample": "%d pack decodes over the first chunk of rank 0's table (same column mix), %.1f s; C restatement of the Java decode, one pack per task" % (mt, dtt),
+            "rows_per_s": round(rpst, 1),
+            "single_thread": {"value": round(gbs1, 3), "unit": "GB/s", "cores": 1, "sample_packs": m1, "seconds": round(dt1, 2)}}
+
+
+def time_with_copies(L, np, device, sample, scratch_gib):
+    """H2D of the compressed packs + decode + D2H of the decoded packs, pinned host memory, on the first chunk."""
+    import ctypes as C
+    descs, arena = sample
+    plan = L.Plan(device, descs, int(scratch_gib * (1 << 30)))
+    in_bytes, out_bytes = len(arena), plan.out_bytes + 16
+    h_in = L.lib.ixr_host_alloc_pinned(in_bytes)
+    h_out = L.lib.ixr_host_alloc_pinned(out_bytes)
+    C.memmove(h_in, arena.ctypes.data, in_bytes)
+    d_in = L.DeviceBuffer(device, in_bytes)
+    d_out = L.DeviceBuffer(device, out_bytes)
+    best = None
+    for it in range(4):
+        L.lib.ixr_dev_synchronize(device)
+        t = time.perf_counter()
+        L.lib.ixr_memcpy_h2d(device, C.c_void_p(d_in.ptr), C.c_void_p(h_in), in_bytes)
+        plan.run(d_in.ptr, in_bytes, d_out.ptr, out_bytes)
+        L.lib.ixr_memcpy_d2h(device, C.c_void_p(h_out), C.c_void_p(d_out.ptr), out_bytes)
+        dt = time.perf_counter() - t
+        if it and (best is None or dt < best):
+            best = dt
+    status, bad = plan.status()
+    res = {"decoded_GBps": round(plan.total_out / best / 1e9, 2), "rows_per_s": round(plan.total_rows / best, 1), "packs": plan.n,
+           "compressed_GB": round(plan.total_in / 1e9, 3), "decoded_GB": round(plan.total_out / 1e9, 3), "bad_packs": int(bad),
+           "note": "synchronous H2D -> decode -> D2H from/to pinned host memory, no overlap"}
+    plan.destroy(); d_in.free(); d_out.free()
+    L.lib.ixr_host_free_pinned(h_in); L.lib.ixr_host_free_pinned(h_out)
+    return res
+
+
+if __name__ == "__main__":
+    main()

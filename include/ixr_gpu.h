@@ -110,6 +110,11 @@ void      ixr_plan_totals(const ixr_plan* plan, uint64_t* in_bytes, uint64_t* ou
  * ixr_plan_set_profiling) of the kernels of the last run; returns the number of entries written (<= cap). */
 void      ixr_plan_set_profiling(ixr_plan* plan, int32_t enabled);
 int32_t   ixr_plan_kernel_times(ixr_plan* plan, const char** names, float* ms, int32_t* launches, int32_t cap);
+/* Algorithmic bytes attributed to each kernel of the last run (same order and names as ixr_plan_kernel_times, valid after
+ * ixr_plan_status): every compressed byte of a pack is attributed to the kernel that consumes it and every decoded byte
+ * to the kernel that produces it, so the entries add up to sum(pack_size) + sum(data_size); traffic to and from scratch
+ * memory is not counted. */
+int32_t   ixr_plan_kernel_bytes(ixr_plan* plan, uint64_t* alg_bytes, int32_t cap);
 
 /* ---- dictionary form on device ------------------------------------------------------------------------------------
  * Replaces PackCompressor_VLT.getDictStruct (:172-186) for every DICT_COMPRESS pack of the plan: writes the

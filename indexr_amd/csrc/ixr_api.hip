@@ -120,6 +120,7 @@ struct Group {
 struct KernelStat {
     double ms = 0;
     int launches = 0;
+    uint64_t alg_bytes = 0;
 };
 
 struct TimedLaunch {
@@ -340,8 +341,8 @@ extern "C" int32_t ixr_plan_run(ixr_plan* pl, const void* d_in, uint64_t in_byte
     if (rc) return rc;
     HIP_TRY(hipSetDevice(pl->device), return IXR_ERR_HIP);
     hipStream_t st = (hipStream_t)stream;
-    pl->timed.clear();
-    pl->event_used = 0;
+    // Timed launches accumulate over successive runs until ixr_plan_status collects them (bounded, in case nobody does).
+    if (pl->timed.size() > 200000) { pl->timed.clear(); pl->event_used = 0; }
     Timer T{pl, st};
     LaunchCtx c{st, pl->d_packs, pl->d_metas, (const uint8_t*)d_in, (uint8_t*)d_out, pl->d_scratch};
     const int* L = pl->d_lists;
@@ -390,7 +391,42 @@ extern "C" int32_t ixr_plan_run_dict_structs(ixr_plan* pl, const void* d_in, uin
     return 0;
 }
 
-static void collect_times(ixr_plan* pl) {
+// Attribution of a pack's algorithmic bytes (packSize + dataSize) to the kernels that consume / produce them.
+static void attribute_bytes(ixr_plan* pl, const std::vector<PackMeta>& metas, std::map<std::string, uint64_t>& by) {
+    for (int i = 0; i < pl->n; i++) {
+        const ixr_pack_desc& d = pl->descs[i];
+        const PackMeta& m = metas[(size_t)i];
+        const uint64_t ps = (uint64_t)d.pack_size, ds = (uint64_t)d.data_size, n = (uint64_t)d.obj_count;
+        const bool w32 = d.data_type == IXR_INT || d.data_type == IXR_FLOAT;
+        if (m.status < 0) continue;
+        switch (m.kind) {
+            case K_RAW: by["k_copy_raw"] += ps + ds; break;
+            case K_DELTA_NUM: by[w32 ? "k_delta<u32>" : "k_delta<u64>"] += ps + ds; break;
+            case K_DICT_NUM:
+                by[w32 ? "k_delta<u32>" : "k_delta<u64>"] += m.ids_off;                     // header + entries
+                by[w32 ? "k_dict_num<u32>" : "k_dict_num<u64>"] += (ps - m.ids_off) + ds;   // id stream in, rows out
+                break;
+            case K_DICT_STR: {
+                const uint64_t index = 4 * (n + 1), body = ds > index ? ds - index : 0;
+                if (m.entries_plain) by["k_str_dict_scan"] += m.ids_off;
+                else { by["k_delta<u32>(str lens)"] += m.sfx_off; by["k_front_decode"] += m.sfx_len; }
+                by["k_str_rows"] += (ps - m.ids_off) + index;
+                by["k_str_copy"] += body;
+                break;
+            }
+            case K_DELTA_STR: {
+                const uint64_t index = 4 * (n + 1), body = ds > index ? ds - index : 0;
+                by["k_delta<u32>(str lens)"] += m.sfx_off;
+                by["k_str_dict_scan"] += index;
+                by["k_front_decode"] += m.sfx_len + body;
+                break;
+            }
+            default: break;
+        }
+    }
+}
+
+static void collect_times(ixr_plan* pl, const std::vector<PackMeta>& metas) {
     pl->stats.clear();
     std::map<std::string, size_t> idx;
     for (const TimedLaunch& t : pl->timed) {
@@ -405,6 +441,11 @@ static void collect_times(ixr_plan* pl) {
         pl->stats[it->second].second.ms += ms;
         pl->stats[it->second].second.launches += 1;
     }
+    std::map<std::string, uint64_t> by;
+    attribute_bytes(pl, metas, by);
+    for (auto& kv : pl->stats) kv.second.alg_bytes = by[kv.first];
+    pl->timed.clear();
+    pl->event_used = 0;
 }
 
 extern "C" int32_t ixr_plan_status(ixr_plan* pl, int32_t* status, void* stream) {
@@ -418,7 +459,7 @@ extern "C" int32_t ixr_plan_status(ixr_plan* pl, int32_t* status, void* stream) 
         status[i] = metas[i].status;
         if (status[i] != pl->descs[i].pack_size) bad++;
     }
-    if (pl->profiling) collect_times(pl);
+    if (pl->profiling || !pl->timed.empty()) collect_times(pl, metas);
     return bad;
 }
 
@@ -449,6 +490,16 @@ extern "C" int32_t ixr_plan_checksums(ixr_plan* pl, const void* d_out, uint64_t 
     (void)hipFree(d_sums);
     if (e != hipSuccess) return fail(IXR_ERR_HIP, "checksum failed: %s", hipGetErrorString(e));
     return 0;
+}
+
+extern "C" int32_t ixr_plan_kernel_bytes(ixr_plan* pl, uint64_t* alg_bytes, int32_t cap) {
+    if (!pl || !alg_bytes) return 0;
+    int n = 0;
+    for (auto& kv : pl->stats) {
+        if (n >= cap) break;
+        alg_bytes[n++] = kv.second.alg_bytes;
+    }
+    return n;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -183,6 +183,49 @@ template <typename T> int plain_search(const T* e, int m, T key) {
     return -1;
 }
 
+// Open-addressing set/map over 64-bit keys used to find the distinct values of a pack before sorting them.
+struct KeyMap {
+    std::vector<uint64_t> keys;
+    std::vector<int32_t> vals;  // -1 = empty slot
+    uint64_t mask;
+    explicit KeyMap(size_t n) {
+        size_t cap = 16;
+        while (cap < 2 * n) cap <<= 1;
+        keys.assign(cap, 0);
+        vals.assign(cap, -1);
+        mask = cap - 1;
+    }
+    static inline uint64_t mix(uint64_t k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; return k; }
+    // returns the slot of `k`, inserting it with value `v` when absent; *fresh tells which
+    inline size_t upsert(uint64_t k, int32_t v, bool* fresh) {
+        size_t i = (size_t)(mix(k) & mask);
+        for (;;) {
+            if (vals[i] < 0) { keys[i] = k; vals[i] = v; *fresh = true; return i; }
+            if (keys[i] == k) { *fresh = false; return i; }
+            i = (i + 1) & mask;
+        }
+    }
+    inline int32_t get(uint64_t k) const {
+        size_t i = (size_t)(mix(k) & mask);
+        for (;;) {
+            if (vals[i] < 0) return -1;
+            if (keys[i] == k) return vals[i];
+            i = (i + 1) & mask;
+        }
+    }
+    inline void set(uint64_t k, int32_t v) { bool f; vals[upsert(k, v, &f)] = v; }
+};
+
+inline uint64_t hash_bytes(const uint8_t* p, int len) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)len;
+    int i = 0;
+    for (; i + 8 <= len; i += 8) { uint64_t w; memcpy(&w, p + i, 8); h = (h ^ w) * 0xff51afd7ed558ccdull; h ^= h >> 29; }
+    uint64_t w = 0;
+    if (i < len) memcpy(&w, p + i, (size_t)(len - i));
+    h = (h ^ w) * 0xc4ceb9fe1a85ec53ull;
+    return h ^ (h >> 32);
+}
+
 struct Dict {
     int entry_count = 0;
     std::vector<uint8_t> entries;  // numbers: raw LE array ; strings: StringsStruct
@@ -190,90 +233,109 @@ struct Dict {
 };
 
 // returns false when the dictionary would exceed ceil(n * ratio) entries (DATA_IMPROPER)
+// Distinct values of a numeric column as order-preserving unsigned keys, ascending in the dictionary's order.
+// key(x): int32/int64 -> offset binary; float/double -> fkey/dkey (Float.compare order, NaNs collapsed).
+template <typename Bits, typename KeyFn>
+static bool numeric_dict(int n, const uint8_t* data, int maxe, KeyFn key, bool is_fp, Dict& d) {
+    KeyMap map((size_t)n);
+    std::vector<uint64_t> uniq;
+    uniq.reserve(1024);
+    std::vector<Bits> first_bits;  // bit pattern of the first row that produced each distinct key (matters for NaN payloads)
+    std::vector<uint64_t> rowkey((size_t)n);
+    for (int i = 0; i < n; i++) {
+        Bits b;
+        memcpy(&b, data + (size_t)i * sizeof(Bits), sizeof(Bits));
+        const uint64_t k = key(b);
+        rowkey[(size_t)i] = k;
+        bool fresh;
+        map.upsert(k, (int32_t)uniq.size(), &fresh);
+        if (fresh) { uniq.push_back(k); first_bits.push_back(b); }
+    }
+    if ((int)uniq.size() > maxe) return false;
+    std::vector<int32_t> order(uniq.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = (int32_t)i;
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return uniq[(size_t)a] < uniq[(size_t)b]; });
+    std::vector<Bits> entries(uniq.size());
+    for (size_t r = 0; r < order.size(); r++) {
+        entries[r] = first_bits[(size_t)order[r]];
+        map.set(uniq[(size_t)order[r]], (int32_t)r);
+    }
+    d.entry_count = (int)entries.size();
+    d.entries.assign((const uint8_t*)entries.data(), (const uint8_t*)entries.data() + entries.size() * sizeof(Bits));
+    for (int i = 0; i < n; i++) d.ids[(size_t)i] = (uint32_t)map.get(rowkey[(size_t)i]);
+    if (is_fp) {
+        // The reference looks rows up with a plain </> binary search on the primitive (fastutil binarySearch): zeros of
+        // either sign compare equal there and a NaN compares equal to whatever is probed first. Redo those rows that way.
+        for (int i = 0; i < n; i++) {
+            Bits b;
+            memcpy(&b, data + (size_t)i * sizeof(Bits), sizeof(Bits));
+            bool special;
+            if constexpr (sizeof(Bits) == 4) special = (b & 0x7fffffffu) == 0 || (b & 0x7fffffffu) > 0x7f800000u;
+            else special = (b & 0x7fffffffffffffffull) == 0 || (b & 0x7fffffffffffffffull) > 0x7ff0000000000000ull;
+            if (!special) continue;
+            int id;
+            if constexpr (sizeof(Bits) == 4) { float f; memcpy(&f, &b, 4); id = plain_search((const float*)entries.data(), (int)entries.size(), f); }
+            else { double f; memcpy(&f, &b, 8); id = plain_search((const double*)entries.data(), (int)entries.size(), f); }
+            if (id < 0) return false;
+            d.ids[(size_t)i] = (uint32_t)id;
+        }
+    }
+    return true;
+}
+
+// returns false when the dictionary would exceed ceil(n * ratio) entries (DATA_IMPROPER)
 bool build_dict(int data_type, float ratio, int n, const uint8_t* data, Dict& d) {
     const int maxe = max_entries(n, ratio);
     d.ids.resize((size_t)n);
     switch (data_type) {
-        case IXR_INT: {
-            std::vector<int32_t> e((size_t)n);
-            memcpy(e.data(), data, (size_t)n * 4);
-            std::sort(e.begin(), e.end());
-            e.erase(std::unique(e.begin(), e.end()), e.end());
-            if ((int)e.size() > maxe) return false;
-            const int32_t* v = (const int32_t*)data;
-            for (int i = 0; i < n; i++) { int32_t x; memcpy(&x, &v[i], 4); d.ids[(size_t)i] = (uint32_t)(std::lower_bound(e.begin(), e.end(), x) - e.begin()); }
-            d.entry_count = (int)e.size();
-            d.entries.assign((const uint8_t*)e.data(), (const uint8_t*)e.data() + e.size() * 4);
-            return true;
-        }
-        case IXR_LONG: {
-            std::vector<int64_t> e((size_t)n);
-            memcpy(e.data(), data, (size_t)n * 8);
-            std::sort(e.begin(), e.end());
-            e.erase(std::unique(e.begin(), e.end()), e.end());
-            if ((int)e.size() > maxe) return false;
-            for (int i = 0; i < n; i++) { int64_t x; memcpy(&x, data + (size_t)i * 8, 8); d.ids[(size_t)i] = (uint32_t)(std::lower_bound(e.begin(), e.end(), x) - e.begin()); }
-            d.entry_count = (int)e.size();
-            d.entries.assign((const uint8_t*)e.data(), (const uint8_t*)e.data() + e.size() * 8);
-            return true;
-        }
-        case IXR_FLOAT: {
-            // (key, first index) so that of several NaN payloads the first one seen is the entry, as an insert-if-absent set keeps it
-            std::vector<std::pair<uint32_t, int>> k((size_t)n);
-            for (int i = 0; i < n; i++) { uint32_t b; memcpy(&b, data + (size_t)i * 4, 4); k[(size_t)i] = {fkey(b), i}; }
-            std::sort(k.begin(), k.end());
-            std::vector<float> e;
-            uint32_t last = 0;
-            for (size_t i = 0; i < k.size(); i++)
-                if (i == 0 || k[i].first != last) { float f; memcpy(&f, data + (size_t)k[i].second * 4, 4); e.push_back(f); last = k[i].first; }
-            if ((int)e.size() > maxe) return false;
-            for (int i = 0; i < n; i++) { float f; memcpy(&f, data + (size_t)i * 4, 4); int id = plain_search(e.data(), (int)e.size(), f); if (id < 0) return false; d.ids[(size_t)i] = (uint32_t)id; }
-            d.entry_count = (int)e.size();
-            d.entries.assign((const uint8_t*)e.data(), (const uint8_t*)e.data() + e.size() * 4);
-            return true;
-        }
-        case IXR_DOUBLE: {
-            std::vector<std::pair<uint64_t, int>> k((size_t)n);
-            for (int i = 0; i < n; i++) { uint64_t b; memcpy(&b, data + (size_t)i * 8, 8); k[(size_t)i] = {dkey(b), i}; }
-            std::sort(k.begin(), k.end());
-            std::vector<double> e;
-            uint64_t last = 0;
-            for (size_t i = 0; i < k.size(); i++)
-                if (i == 0 || k[i].first != last) { double f; memcpy(&f, data + (size_t)k[i].second * 8, 8); e.push_back(f); last = k[i].first; }
-            if ((int)e.size() > maxe) return false;
-            for (int i = 0; i < n; i++) { double f; memcpy(&f, data + (size_t)i * 8, 8); int id = plain_search(e.data(), (int)e.size(), f); if (id < 0) return false; d.ids[(size_t)i] = (uint32_t)id; }
-            d.entry_count = (int)e.size();
-            d.entries.assign((const uint8_t*)e.data(), (const uint8_t*)e.data() + e.size() * 8);
-            return true;
-        }
+        case IXR_INT:
+            return numeric_dict<uint32_t>(n, data, maxe, [](uint32_t b) { return (uint64_t)(b ^ 0x80000000u); }, false, d);
+        case IXR_LONG:
+            return numeric_dict<uint64_t>(n, data, maxe, [](uint64_t b) { return b ^ 0x8000000000000000ull; }, false, d);
+        case IXR_FLOAT:
+            return numeric_dict<uint32_t>(n, data, maxe, [](uint32_t b) { return (uint64_t)fkey(b); }, true, d);
+        case IXR_DOUBLE:
+            return numeric_dict<uint64_t>(n, data, maxe, [](uint64_t b) { return dkey(b); }, true, d);
         case IXR_STRING: {
             const uint8_t* body = data + 4 * ((size_t)n + 1);
             auto off = [&](int i) { int32_t o; memcpy(&o, data + 4 * (size_t)i, 4); return o; };
-            std::vector<StrRef> rows((size_t)n);
-            for (int i = 0; i < n; i++) rows[(size_t)i] = {body + off(i), off(i + 1) - off(i)};
-            std::vector<int> order((size_t)n);
-            for (int i = 0; i < n; i++) order[(size_t)i] = i;
-            std::sort(order.begin(), order.end(), [&](int a, int b) { return cmp_bytes(rows[(size_t)a], rows[(size_t)b]) < 0; });
-            std::vector<StrRef> e;
+            // distinct strings through a hash of the bytes (collisions resolved by comparing), then sort only those
+            KeyMap map((size_t)n);
+            std::vector<StrRef> uniq;
+            std::vector<int32_t> row_u((size_t)n);
             for (int i = 0; i < n; i++) {
-                const StrRef& r = rows[(size_t)order[(size_t)i]];
-                if (e.empty() || cmp_bytes(e.back(), r) != 0) e.push_back(r);
-                d.ids[(size_t)order[(size_t)i]] = (uint32_t)(e.size() - 1);
+                StrRef r{body + off(i), off(i + 1) - off(i)};
+                uint64_t h = hash_bytes(r.p, r.len);
+                for (;;) {  // linear re-hash on a (rare) collision of different strings
+                    bool fresh;
+                    size_t slot = map.upsert(h, (int32_t)uniq.size(), &fresh);
+                    if (fresh) { uniq.push_back(r); row_u[(size_t)i] = (int32_t)uniq.size() - 1; break; }
+                    const StrRef& e = uniq[(size_t)map.vals[slot]];
+                    if (e.len == r.len && (r.len == 0 || memcmp(e.p, r.p, (size_t)r.len) == 0)) { row_u[(size_t)i] = map.vals[slot]; break; }
+                    h = KeyMap::mix(h + 0x9E3779B97F4A7C15ull);
+                }
             }
-            if ((int)e.size() > maxe) return false;
-            d.entry_count = (int)e.size();
+            if ((int)uniq.size() > maxe) return false;
+            std::vector<int32_t> order(uniq.size());
+            for (size_t i = 0; i < order.size(); i++) order[i] = (int32_t)i;
+            std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cmp_bytes(uniq[(size_t)a], uniq[(size_t)b]) < 0; });
+            std::vector<int32_t> rank(uniq.size());
+            for (size_t r = 0; r < order.size(); r++) rank[(size_t)order[r]] = (int32_t)r;
+            for (int i = 0; i < n; i++) d.ids[(size_t)i] = (uint32_t)rank[(size_t)row_u[(size_t)i]];
+            d.entry_count = (int)uniq.size();
             size_t total = 0;
-            for (auto& r : e) total += (size_t)r.len;
-            d.entries.resize(4 * (e.size() + 1) + total);
+            for (auto& r : uniq) total += (size_t)r.len;
+            d.entries.resize(4 * (uniq.size() + 1) + total);
             uint8_t* idx = d.entries.data();
-            uint8_t* b = idx + 4 * (e.size() + 1);
+            uint8_t* b = idx + 4 * (uniq.size() + 1);
             int32_t o = 0;
-            for (size_t i = 0; i < e.size(); i++) {
+            for (size_t i = 0; i < order.size(); i++) {
+                const StrRef& e = uniq[(size_t)order[i]];
                 memcpy(idx + 4 * i, &o, 4);
-                memcpy(b + o, e[i].p, (size_t)e[i].len);
-                o += e[i].len;
+                if (e.len) memcpy(b + o, e.p, (size_t)e.len);
+                o += e.len;
             }
-            memcpy(idx + 4 * e.size(), &o, 4);
+            memcpy(idx + 4 * uniq.size(), &o, 4);
             return true;
         }
     }

@@ -49,6 +49,7 @@ struct Tables {
     std::vector<std::string> urls;  // 50000 URLs
     std::vector<double> zipf_cdf;   // Zipf(1.1) over the URLs
     std::vector<int64_t> lcard;     // 4096 sparse longs
+    std::vector<uint32_t> zipf_bucket;  // first URL index whose cdf reaches k/4096: narrows the search per draw
     explicit Tables(uint64_t sd) : seed(sd) {
         Rng r(sd ^ 0xA5A5A5A5DEADBEEFull);
         for (int i = 0; i < 32; i++) {
@@ -78,6 +79,9 @@ struct Tables {
         double acc = 0;
         for (int i = 0; i < 50000; i++) { acc += 1.0 / std::pow((double)(i + 1), 1.1); zipf_cdf[(size_t)i] = acc; }
         for (auto& v : zipf_cdf) v /= acc;
+        zipf_bucket.resize(4097);
+        for (int k = 0; k <= 4096; k++)
+            zipf_bucket[(size_t)k] = (uint32_t)(std::lower_bound(zipf_cdf.begin(), zipf_cdf.end(), (double)k / 4096.0) - zipf_cdf.begin());
         lcard.resize(4096);
         for (auto& v : lcard) v = (int64_t)(r.next() & ((1ull << 40) - 1));
     }
@@ -194,7 +198,10 @@ extern "C" int32_t ixr_synth_column(int32_t kind, uint64_t seed, uint32_t pack_i
             StrBuilder b;
             for (int i = 0; i < n; i++) {
                 double u = r.unit();
-                size_t k = (size_t)(std::lower_bound(t->zipf_cdf.begin(), t->zipf_cdf.end(), u) - t->zipf_cdf.begin());
+                const size_t bk = (size_t)(u * 4096.0);
+                auto lo = t->zipf_cdf.begin() + t->zipf_bucket[bk];
+                auto hi = t->zipf_cdf.begin() + std::min<size_t>(t->zipf_bucket[bk + 1] + 1, t->zipf_cdf.size());
+                size_t k = (size_t)(std::lower_bound(lo, hi, u) - t->zipf_cdf.begin());
                 if (k >= t->urls.size()) k = t->urls.size() - 1;
                 const std::string& s = t->urls[k];
                 b.add(s.data(), s.size());

@@ -67,6 +67,7 @@ _sig = {
     "ixr_plan_totals": (None, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
     "ixr_plan_set_profiling": (None, [_vp, _i32]),
     "ixr_plan_kernel_times": (_i32, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(_i32), _i32]),
+    "ixr_plan_kernel_bytes": (_i32, [_vp, C.POINTER(_u64), _i32]),
     "ixr_plan_run_dict_structs": (_i32, [_vp, _vp, _u64, _vp, _u64, C.POINTER(_u64), _vp]),
     "ixr_decode_pack": (_i32, [_i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32]),
     "ixr_get_dict_struct": (_i32, [_i32, _i32, _i32, _vp, _i32, _vp, _i32]),
@@ -230,7 +231,9 @@ class Plan:
         ms = (C.c_float * cap)()
         launches = (_i32 * cap)()
         k = lib.ixr_plan_kernel_times(self.handle, names, ms, launches, cap)
-        return [(names[i].decode(), float(ms[i]), int(launches[i])) for i in range(k)]
+        alg = (_u64 * cap)()
+        lib.ixr_plan_kernel_bytes(self.handle, alg, cap)
+        return [(names[i].decode(), float(ms[i]), int(launches[i]), int(alg[i])) for i in range(k)]
 
     def destroy(self):
         if self.handle:
