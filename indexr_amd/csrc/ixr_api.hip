@@ -148,37 +148,42 @@ struct ixr_plan {
     std::vector<hipEvent_t> event_pool;   // reused across runs
     size_t event_used = 0;
     std::vector<std::pair<std::string, KernelStat>> stats;
-    bool ds_offsets_uploaded = false;
+    int all_off = 0;  // offset of the identity list (all packs) in d_lists
 };
 
-static uint64_t pack_scratch_layout(DevPack& p, uint64_t dict_cap_override) {
-    // Lays the scratch regions of one pack out from obj_count / data_size alone; returns the bytes used.
-    uint64_t o = 0;
+// Lays the scratch regions of one pack out from obj_count / data_size alone.  Two areas:
+//   index area (kept for the whole plan, filled by one k_parse launch over all packs): DELTA indexes, RLE restart points
+//   bulk area  (reused group after group): decoded dictionaries, string length arrays, per-row source offsets
+// Offsets are written relative to each area's start; the caller rebases them.  Returns the bytes used in each.
+struct ScratchNeed { uint64_t index, bulk; };
+static ScratchNeed pack_scratch_layout(DevPack& p, uint64_t dict_cap_override) {
+    uint64_t oi = 0, ob = 0;
     const uint64_t cap = (uint64_t)p.obj_count;
     const uint64_t idx = align16(8 * ((cap + kBlock - 1) / kBlock) + 4 * ((cap + kMini - 1) / kMini));
-    auto take = [&](uint64_t bytes) { uint64_t r = o; o += align16(bytes); return r; };
+    auto take_i = [&](uint64_t bytes) { uint64_t r = oi; oi += align16(bytes); return r; };
+    auto take_b = [&](uint64_t bytes) { uint64_t r = ob; ob += align16(bytes); return r; };
     p.s_idx[0] = p.s_idx[1] = p.s_dict = p.s_restart = p.s_lens = p.s_rows = 0;
     p.dict_cap = 0;
-    if (p.encode_type == IXR_ENC_RAW) return 0;
-    p.s_idx[0] = take(idx);
+    if (p.encode_type == IXR_ENC_RAW) return {0, 0};
+    p.s_idx[0] = take_i(idx);
     const bool dict = p.encode_type == IXR_ENC_DICT_COMPRESS || p.encode_type == IXR_ENC_SIMPLE_DICT;
     if (p.width) {
         if (dict) {
             p.dict_cap = dict_cap_override ? dict_cap_override : cap * (uint64_t)(p.width / 8);
-            p.s_dict = take(p.dict_cap + 16);
-            p.s_restart = take(8 * ((cap + kRleTile - 1) / kRleTile));
+            p.s_dict = take_b(p.dict_cap + 16);
+            p.s_restart = take_i(8 * ((cap + kRleTile - 1) / kRleTile));
         }
     } else {
-        p.s_idx[1] = take(idx);
-        p.s_lens = take(4ull * 3 * lens_stride(p.obj_count));
+        p.s_idx[1] = take_i(idx);
+        p.s_lens = take_b(4ull * 3 * lens_stride(p.obj_count));
         if (dict) {
             p.dict_cap = dict_cap_override ? dict_cap_override : (uint64_t)p.data_size;
-            p.s_dict = take(p.dict_cap + 32);
-            p.s_rows = take(4 * cap + 16);
-            p.s_restart = take(8 * ((cap + kRleTile - 1) / kRleTile));
+            p.s_dict = take_b(p.dict_cap + 32);
+            p.s_rows = take_b(4 * cap + 16);
+            p.s_restart = take_i(8 * ((cap + kRleTile - 1) / kRleTile));
         }
     }
-    return o;
+    return {oi, ob};
 }
 
 extern "C" void ixr_plan_destroy(ixr_plan* plan) {
@@ -205,7 +210,7 @@ static ixr_plan* plan_create(int32_t device, const ixr_pack_desc* descs, int32_t
     std::vector<int> lists;
     Group g;
     std::vector<int> cls[L_COUNT];
-    uint64_t gs = 0;
+    uint64_t gs = 0, index_total = 0, bulk_max = 0;
     auto flush = [&]() {
         if (cls[L_ALL].empty()) return;
         for (int c = 0; c < L_COUNT; c++) {
@@ -216,7 +221,7 @@ static ixr_plan* plan_create(int32_t device, const ixr_pack_desc* descs, int32_t
         }
         g.scratch = gs;
         pl->groups.push_back(g);
-        pl->scratch_bytes = std::max(pl->scratch_bytes, gs);
+        bulk_max = std::max(bulk_max, gs);
         gs = 0;
     };
     for (int i = 0; i < n_packs; i++) {
@@ -232,11 +237,13 @@ static ixr_plan* plan_create(int32_t device, const ixr_pack_desc* descs, int32_t
         p.obj_count = d.obj_count; p.encode_type = d.encode_type; p.data_type = d.data_type;
         p.width = (d.data_type == IXR_INT || d.data_type == IXR_FLOAT) ? 32 : (d.data_type == IXR_STRING ? 0 : 64);
         p.ds_off = 0;
-        uint64_t need = pack_scratch_layout(p, dict_cap_override);
-        if ((gs + need > scratch_budget && !cls[L_ALL].empty()) || (int)cls[L_ALL].size() >= kMaxGroupPacks) flush();
-        // offsets are relative to the group's scratch base
-        p.s_idx[0] += gs; p.s_idx[1] += gs; p.s_dict += gs; p.s_restart += gs; p.s_lens += gs; p.s_rows += gs;
-        gs += need;
+        ScratchNeed need = pack_scratch_layout(p, dict_cap_override);
+        if ((gs + need.bulk > scratch_budget && !cls[L_ALL].empty()) || (int)cls[L_ALL].size() >= kMaxGroupPacks) flush();
+        // index offsets are relative to the index area, bulk offsets to the group's bulk area; rebased below
+        p.s_idx[0] += index_total; p.s_idx[1] += index_total; p.s_restart += index_total;
+        p.s_dict += gs; p.s_lens += gs; p.s_rows += gs;
+        index_total += need.index;
+        gs += need.bulk;
         cls[L_ALL].push_back(i);
         if (d.encode_type == IXR_ENC_RAW) cls[L_RAW].push_back(i);
         else if (p.width == 32) cls[L_N32].push_back(i);
@@ -248,6 +255,17 @@ static ixr_plan* plan_create(int32_t device, const ixr_pack_desc* descs, int32_t
         pl->tot_in += (uint64_t)d.pack_size; pl->tot_out += (uint64_t)d.data_size; pl->tot_rows += (uint64_t)d.obj_count;
     }
     flush();
+    // one allocation: [index area of all packs][bulk area of the largest group]; make the bulk offsets absolute
+    index_total = align16(index_total) + 64;  // the bulk area never starts at offset 0 (k_str_copy may read 15 bytes before a dictionary)
+    for (int i = 0; i < n_packs; i++) {
+        DevPack& p = pl->hpacks[i];
+        if (p.encode_type == IXR_ENC_RAW) continue;
+        p.s_dict += index_total; p.s_lens += index_total; p.s_rows += index_total;
+    }
+    pl->scratch_bytes = index_total + bulk_max + 64;
+    // the list of all packs, for the single parse launch
+    pl->all_off = (int)lists.size();
+    for (int i = 0; i < n_packs; i++) lists.push_back(i);
     hipError_t e;
     if ((e = hipMalloc((void**)&pl->d_packs, sizeof(DevPack) * (size_t)n_packs)) != hipSuccess ||
         (e = hipMalloc((void**)&pl->d_metas, sizeof(PackMeta) * (size_t)n_packs)) != hipSuccess ||
@@ -324,15 +342,21 @@ int32_t check_run_args(ixr_plan* pl, const void* d_in, uint64_t in_bytes, void* 
     return 0;
 }
 
-// parse + dictionary construction of one group; shared by the row decode and the DictStruct run
-void run_group_front(ixr_plan* pl, Timer& T, LaunchCtx& c, const Group& g) {
+// framing walk of every pack of the plan: one launch, so that the serial chains of all packs overlap
+void run_parse_all(ixr_plan* pl, Timer& T, LaunchCtx& c) {
+    T.run("k_parse", pl->n, [&] { launch_parse(c, pl->d_lists + pl->all_off, pl->n); });
+}
+// dictionary construction of one group; shared by the row decode and the DictStruct run
+void run_group_front(ixr_plan* pl, Timer& T, LaunchCtx& c, const Group& g, int use_ds) {
     const int* L = pl->d_lists;
-    T.run("k_parse", g.cnt[L_ALL], [&] { launch_parse(c, L + g.off[L_ALL], g.cnt[L_ALL]); });
     T.run("k_delta<u32>", g.cnt[L_N32], [&] { launch_delta(c, L + g.off[L_N32], g.cnt[L_N32], 32, 1); });
     T.run("k_delta<u64>", g.cnt[L_N64], [&] { launch_delta(c, L + g.off[L_N64], g.cnt[L_N64], 64, 1); });
     T.run("k_delta<u32>(str lens)", g.cnt[L_STR], [&] { launch_delta(c, L + g.off[L_STR], g.cnt[L_STR], 32, 2); });
     T.run("k_str_dict_scan", g.cnt[L_STR], [&] { launch_str_dict_scan(c, L + g.off[L_STR], g.cnt[L_STR]); });
-    T.run("k_front_decode", g.cnt[L_STR], [&] { launch_front_decode(c, L + g.off[L_STR], g.cnt[L_STR]); });
+    T.run("k_front_summary", g.cnt[L_STR], [&] { launch_front_summary(c, L + g.off[L_STR], g.cnt[L_STR], use_ds); });
+    T.run("k_front_combine", g.cnt[L_STR], [&] { launch_front_combine(c, L + g.off[L_STR], g.cnt[L_STR], use_ds); });
+    T.run("k_front_decode", g.cnt[L_STR], [&] { launch_front_decode(c, L + g.off[L_STR], g.cnt[L_STR], use_ds); });
+    T.run("k_front_serial", g.cnt[L_STR], [&] { launch_front_serial(c, L + g.off[L_STR], g.cnt[L_STR]); });
 }
 }  // namespace
 
@@ -346,8 +370,9 @@ extern "C" int32_t ixr_plan_run(ixr_plan* pl, const void* d_in, uint64_t in_byte
     Timer T{pl, st};
     LaunchCtx c{st, pl->d_packs, pl->d_metas, (const uint8_t*)d_in, (uint8_t*)d_out, pl->d_scratch};
     const int* L = pl->d_lists;
+    run_parse_all(pl, T, c);
     for (const Group& g : pl->groups) {
-        run_group_front(pl, T, c, g);
+        run_group_front(pl, T, c, g, 0);
         T.run("k_dict_num<u32>", g.cnt[L_N32], [&] { launch_dict_num(c, L + g.off[L_N32], g.cnt[L_N32], 32); });
         T.run("k_dict_num<u64>", g.cnt[L_N64], [&] { launch_dict_num(c, L + g.off[L_N64], g.cnt[L_N64], 64); });
         T.run("k_copy_raw", g.cnt[L_RAW], [&] { launch_copy_raw(c, L + g.off[L_RAW], g.cnt[L_RAW]); });
@@ -383,8 +408,9 @@ extern "C" int32_t ixr_plan_run_dict_structs(ixr_plan* pl, const void* d_in, uin
     Timer T{pl, st};
     LaunchCtx c{st, pl->d_packs, pl->d_metas, (const uint8_t*)d_in, (uint8_t*)d_out, pl->d_scratch};
     const int* L = pl->d_lists;
+    run_parse_all(pl, T, c);
     for (const Group& g : pl->groups) {
-        run_group_front(pl, T, c, g);
+        run_group_front(pl, T, c, g, 1);
         T.run("k_dict_struct", g.cnt[L_DICT], [&] { launch_dict_struct(c, L + g.off[L_DICT], g.cnt[L_DICT]); });
     }
     HIP_TRY(hipGetLastError(), return IXR_ERR_HIP);
@@ -409,7 +435,7 @@ static void attribute_bytes(ixr_plan* pl, const std::vector<PackMeta>& metas, st
             case K_DICT_STR: {
                 const uint64_t index = 4 * (n + 1), body = ds > index ? ds - index : 0;
                 if (m.entries_plain) by["k_str_dict_scan"] += m.ids_off;
-                else { by["k_delta<u32>(str lens)"] += m.sfx_off; by["k_front_decode"] += m.sfx_len; }
+                else { by["k_delta<u32>(str lens)"] += m.sfx_off; by[m.front_blocks ? "k_front_decode" : "k_front_serial"] += m.sfx_len; }
                 by["k_str_rows"] += (ps - m.ids_off) + index;
                 by["k_str_copy"] += body;
                 break;
@@ -418,7 +444,7 @@ static void attribute_bytes(ixr_plan* pl, const std::vector<PackMeta>& metas, st
                 const uint64_t index = 4 * (n + 1), body = ds > index ? ds - index : 0;
                 by["k_delta<u32>(str lens)"] += m.sfx_off;
                 by["k_str_dict_scan"] += index;
-                by["k_front_decode"] += m.sfx_len + body;
+                by["k_front_serial"] += m.sfx_len + body;
                 break;
             }
             default: break;

@@ -10,6 +10,7 @@ constexpr int kBlock = 128;        // values per delta block (one zig-zag varint
 constexpr int kMini = 32;          // values per mini-block (one width byte each)
 constexpr int kRleTile = 1024;     // rows per RLE restart point / per wave tile in the id-expanding kernels
 constexpr int kStrTileRows = 256;  // rows per workgroup tile in the string body copy
+constexpr int kFrontBlock = 64;    // strings per block of the parallel front-coding decode
 
 // Element stride of the per-pack string length arrays (prefixLen / suffixLen / sufOff): obj_count rounded up to 4 so that
 // each array starts 16-byte aligned.
@@ -65,6 +66,8 @@ struct PackMeta {
     uint32_t sfx_len;       // front coding: number of suffix bytes the headers promise
     uint32_t dict_struct_size; // DICT_COMPRESS: the 4-byte uncompressed DictStruct size at the head of the pack
     uint32_t max_len;       // strings: longest dictionary entry (filled by the dictionary scan)
+    uint32_t front_blocks;  // front-coded dictionary: number of 64-string blocks decoded in parallel (0 = serial path)
+    uint32_t front_stride;  // columns per block row of the block-summary array (max_len rounded up to 64)
     StreamDesc s[2];
 };
 

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_parse(const DevPack* __restrict__ packs
 
     PackMeta m;
     m.status = 0; m.kind = K_NONE; m.entry_count = 0; m.id_bw = 0; m.ids_off = 0; m.ids_len = 0; m.entries_off = 0;
-    m.entries_plain = 0; m.sfx_off = 0; m.sfx_len = 0; m.dict_struct_size = 0; m.max_len = 0;
+    m.entries_plain = 0; m.sfx_off = 0; m.sfx_len = 0; m.dict_struct_size = 0; m.max_len = 0; m.front_blocks = 0; m.front_stride = 0;
     m.s[0].n = m.s[1].n = 0; m.s[0].in_off = m.s[1].in_off = 0; m.s[0].first = m.s[1].first = 0;
     int32_t err = 0;
     int64_t consumed = 0;
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void k_delta(const DevPack* __restrict__ packs
         }
         return;
     }
-    const StreamDesc s = M.s[sk];
+    const StreamDesc s = sk == 0 ? M.s[0] : M.s[1];
     if (s.n == 0) return;
 
     U* dst;
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void k_delta(const DevPack* __restrict__ packs
     else if (kind == K_DICT_NUM) dst = (U*)(scratch + P.s_dict);
     else dst = (U*)(scratch + P.s_lens + (size_t)sk * 4 * (size_t)lens_stride(P.obj_count));  // string length streams (always 32 bit)
 
-    const int64_t* min_delta = (const int64_t*)(scratch + P.s_idx[sk]);
+    const int64_t* min_delta = (const int64_t*)(scratch + (sk == 0 ? P.s_idx[0] : P.s_idx[1]));
     const uint32_t* mb = (const uint32_t*)(min_delta + (P.obj_count + kBlock - 1) / kBlock);
     const uint32_t n = s.n;
     const int lane = tid & 63, wave = tid >> 6;
@@ -655,6 +655,13 @@ __global__ __launch_bounds__(256) void k_str_dict_scan(const DevPack* __restrict
             doff[ec] = total_len;
             sufoff[ec] = total_suf;
             M.max_len = mx;
+            // Block-parallel decode needs a (blocks x columns) uint16 summary; it lives in the pack's own, not yet
+            // written, output region.  Front-coded packs (dictionary == output) and oversized cases take the serial path.
+            const uint32_t nblk = (ec + kFrontBlock - 1) / kFrontBlock, stride = (mx + 63u) & ~63u;
+            if (M.kind == K_DICT_STR && nblk > 1 && 2ull * nblk * stride <= (uint64_t)P.data_size) {
+                M.front_blocks = nblk;
+                M.front_stride = stride;
+            }
         }
     }
     if (M.kind == K_DELTA_STR && tot64 + 4ull * (ec + 1) <= cap) {
@@ -666,44 +673,164 @@ __global__ __launch_bounds__(256) void k_str_dict_scan(const DevPack* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_front_decode: expands a front-coded string list (string i = first prefixLen[i] bytes of string i-1 + its suffix,
-// DeltaCodec.java:368-383).  Column parallel: a wave owns 64 byte columns [64g, 64g+64); lane j keeps the current byte
-// of its column in a register while the wave steps through the strings in order -- the prefix of a string is exactly
-// what the registers already hold, only columns covered by the suffix load a new byte.  No dependency between
-// iterations goes through memory, so the loads pipeline.
+// Front-coded string lists (string i = first prefixLen[i] bytes of string i-1 + its suffix, DeltaCodec.java:368-383).
+//
+// Column-parallel core: a wave owns 64 byte columns; lane j keeps the current byte of column j in a register while the
+// wave steps through strings in order -- the prefix of a string is exactly what the registers already hold, only columns
+// covered by the suffix take a new byte.  Nothing flows through memory between iterations.
+//
+// To decode blocks of kFrontBlock strings independently, each block needs the bytes its first strings inherit:
+//   k_front_summary  per block and column: the byte the block's last writer of that column leaves (0xFFFF = none)
+//   k_front_combine  per column, in block order: turns the summaries into "state before the block" (in place)
+//   k_front_decode   per block: the core loop, started from that state
+// The summary array (blocks x columns x uint16) lives in the pack's own output region, which is written only later.
+// Lists that do not qualify (front-coded packs, whose dictionary is the output; one-block lists) use k_front_serial.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_front_decode(const DevPack* __restrict__ packs, const int* __restrict__ list,
+struct FrontCtx {
+    uint32_t ec, nblk, stride;
+    const uint8_t* sfx;
+    const uint32_t* doff;
+    uint8_t* body;
+    const int32_t* pre;
+    const int32_t* suf;
+    const uint32_t* sufoff;
+    uint16_t* sum;
+};
+
+__device__ __forceinline__ bool front_ctx(FrontCtx& f, const DevPack& P, const PackMeta& M, const uint8_t* in, uint8_t* out,
+                                          uint8_t* scratch, int use_ds, bool parallel) {
+    if (M.status < 0 || (M.kind != K_DICT_STR && M.kind != K_DELTA_STR) || M.entries_plain) return false;
+    if ((M.front_blocks != 0) != parallel) return false;
+    f.ec = M.entry_count;
+    f.nblk = M.front_blocks;
+    f.stride = M.front_stride;
+    f.sfx = in + P.in_off + M.sfx_off;
+    uint8_t* dict = str_dict_ptr(P, M, out, scratch);
+    f.doff = (const uint32_t*)dict;
+    f.body = dict + 4ull * (f.ec + 1);
+    f.pre = (const int32_t*)(scratch + P.s_lens);
+    f.suf = f.pre + lens_stride(P.obj_count);
+    f.sufoff = (const uint32_t*)(f.suf + lens_stride(P.obj_count));
+    f.sum = (uint16_t*)(out + (use_ds ? P.ds_off : P.out_off));
+    return true;
+}
+
+__global__ __launch_bounds__(64) void k_front_serial(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                      const PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                      uint8_t* __restrict__ out, uint8_t* __restrict__ scratch) {
     const int pi = list[blockIdx.y];
-    const PackMeta& M = metas[pi];
-    if (M.status < 0 || (M.kind != K_DICT_STR && M.kind != K_DELTA_STR) || M.entries_plain) return;
     const DevPack P = packs[pi];
-    const uint32_t ec = M.entry_count;
-    const uint32_t max_len = M.max_len;
-    const uint8_t* sfx = in + P.in_off + M.sfx_off;
-    uint8_t* dict = str_dict_ptr(P, M, out, scratch);
-    const uint32_t* doff = (const uint32_t*)dict;
-    uint8_t* body = dict + 4ull * (ec + 1);
-    const int32_t* pre = (const int32_t*)(scratch + P.s_lens);
-    const int32_t* suf = pre + lens_stride(P.obj_count);
-    const uint32_t* sufoff = (const uint32_t*)(suf + lens_stride(P.obj_count));
+    FrontCtx f;
+    if (!front_ctx(f, P, metas[pi], in, out, scratch, 0, false)) return;
+    const uint32_t max_len = metas[pi].max_len;
     const int lane = threadIdx.x;
     for (uint32_t col0 = blockIdx.x * 64; col0 < max_len; col0 += gridDim.x * 64) {
         const uint32_t j = col0 + lane;
         uint32_t cur = 0;
-        for (uint32_t i0 = 0; i0 < ec; i0 += 64) {
-            // each lane fetches the metadata of one string, then the wave steps through the 64 strings
-            const uint32_t ii = min(i0 + lane, ec - 1);
-            const uint32_t mp = (uint32_t)pre[ii], ms = (uint32_t)suf[ii], mo = doff[ii], mso = sufoff[ii];
-            const uint32_t cnt = min(64u, ec - i0);
+        for (uint32_t i0 = 0; i0 < f.ec; i0 += 64) {
+            const uint32_t ii = min(i0 + lane, f.ec - 1);
+            const uint32_t mp = (uint32_t)f.pre[ii], ms = (uint32_t)f.suf[ii], mo = f.doff[ii], mso = f.sufoff[ii];
+            const uint32_t cnt = min(64u, f.ec - i0);
             for (uint32_t k = 0; k < cnt; k++) {
-                const uint32_t p = __shfl(mp, k), s = __shfl(ms, k);
-                const uint32_t len = p + s;
+                const uint32_t p = __builtin_amdgcn_readlane(mp, k), sl = __builtin_amdgcn_readlane(ms, k);
+                const uint32_t len = p + sl;
                 if (len <= col0) continue;  // uniform: nothing of this string lies in our columns
-                const uint32_t o = __shfl(mo, k), so = __shfl(mso, k);
-                if (j >= p && j < len) cur = sfx[so + (j - p)];
-                if (j < len) body[o + j] = (uint8_t)cur;
+                const uint32_t o = __builtin_amdgcn_readlane(mo, k), so = __builtin_amdgcn_readlane(mso, k);
+                if (j >= p && j < len) cur = f.sfx[so + (j - p)];
+                if (j < len) f.body[o + j] = (uint8_t)cur;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_front_summary(const DevPack* __restrict__ packs, const int* __restrict__ list,
+                                                       const PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
+                                                       uint8_t* __restrict__ out, uint8_t* __restrict__ scratch, int use_ds) {
+    const int pi = list[blockIdx.y];
+    const DevPack P = packs[pi];
+    FrontCtx f;
+    if (!front_ctx(f, P, metas[pi], in, out, scratch, use_ds, true)) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (uint32_t b = wave; b < f.nblk; b += nwaves) {
+        const uint32_t i0 = b * kFrontBlock;
+        const uint32_t cnt = min((uint32_t)kFrontBlock, f.ec - i0);
+        const uint32_t ii = min(i0 + lane, f.ec - 1);
+        const uint32_t mp = (uint32_t)f.pre[ii], mlen = mp + (uint32_t)f.suf[ii], mso = f.sufoff[ii];
+        for (uint32_t col0 = 0; col0 < f.stride; col0 += 64) {
+            const uint32_t j = col0 + lane;
+            int w = -1;
+            for (uint32_t k = 0; k < cnt; k++) {
+                const uint32_t p = __builtin_amdgcn_readlane(mp, k), l = __builtin_amdgcn_readlane(mlen, k);
+                if (j >= p && j < l) w = (int)k;
+            }
+            const int src = w < 0 ? 0 : w;
+            const uint32_t wp = __shfl(mp, src), wso = __shfl(mso, src);
+            uint32_t val = 0xFFFFu;
+            if (w >= 0) val = f.sfx[wso + (j - wp)];
+            f.sum[(size_t)b * f.stride + j] = (uint16_t)val;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_front_combine(const DevPack* __restrict__ packs, const int* __restrict__ list,
+                                                      const PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
+                                                      uint8_t* __restrict__ out, uint8_t* __restrict__ scratch, int use_ds) {
+    const int pi = list[blockIdx.y];
+    const DevPack P = packs[pi];
+    FrontCtx f;
+    if (!front_ctx(f, P, metas[pi], in, out, scratch, use_ds, true)) return;
+    const int lane = threadIdx.x;
+    for (uint32_t col0 = blockIdx.x * 64; col0 < f.stride; col0 += gridDim.x * 64) {
+        uint16_t* col = f.sum + col0 + lane;
+        uint32_t state = 0;
+        uint32_t b = 0;
+        for (; b + 8 <= f.nblk; b += 8) {
+            uint32_t t[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) t[q] = col[(size_t)(b + q) * f.stride];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                col[(size_t)(b + q) * f.stride] = (uint16_t)state;
+                if (t[q] != 0xFFFFu) state = t[q];
+            }
+        }
+        for (; b < f.nblk; b++) {
+            const uint32_t t = col[(size_t)b * f.stride];
+            col[(size_t)b * f.stride] = (uint16_t)state;
+            if (t != 0xFFFFu) state = t;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_front_decode(const DevPack* __restrict__ packs, const int* __restrict__ list,
+                                                      const PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
+                                                      uint8_t* __restrict__ out, uint8_t* __restrict__ scratch, int use_ds) {
+    const int pi = list[blockIdx.y];
+    const DevPack P = packs[pi];
+    FrontCtx f;
+    if (!front_ctx(f, P, metas[pi], in, out, scratch, use_ds, true)) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (uint32_t b = wave; b < f.nblk; b += nwaves) {
+        const uint32_t i0 = b * kFrontBlock;
+        const uint32_t cnt = min((uint32_t)kFrontBlock, f.ec - i0);
+        const uint32_t ii = min(i0 + lane, f.ec - 1);
+        const uint32_t mp = (uint32_t)f.pre[ii], ms = (uint32_t)f.suf[ii], mo = f.doff[ii], mso = f.sufoff[ii];
+        for (uint32_t col0 = 0; col0 < f.stride; col0 += 64) {
+            const uint32_t j = col0 + lane;
+            uint32_t cur = f.sum[(size_t)b * f.stride + j];
+#pragma unroll 4
+            for (uint32_t k = 0; k < cnt; k++) {
+                const uint32_t p = __builtin_amdgcn_readlane(mp, k), sl = __builtin_amdgcn_readlane(ms, k);
+                const uint32_t len = p + sl;
+                if (len <= col0) continue;  // uniform
+                const uint32_t o = __builtin_amdgcn_readlane(mo, k), so = __builtin_amdgcn_readlane(mso, k);
+                const bool in_suffix = j >= p && j < len;
+                // unconditional, clamped load (so + 0 is always readable: suffix bytes are followed by the id stream)
+                const uint32_t t = f.sfx[so + (in_suffix ? j - p : 0u)];
+                cur = in_suffix ? t : cur;
+                if (j < len) f.body[o + j] = (uint8_t)cur;
             }
         }
     }
@@ -782,11 +909,26 @@ __global__ __launch_bounds__(256) void k_row_scan(const DevPack* __restrict__ pa
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_str_copy: string dictionary packs: body[offset[i] .. offset[i+1]) = dictBody[srcOff[i] ..].  One workgroup per tile of
-// kStrTileRows rows; the tile's offsets and source offsets are staged in LDS; each lane produces one aligned 4-byte
-// word of the output body per step (binary search of the word's first byte in the staged offsets, then a short walk for
-// words that straddle rows), so stores are fully coalesced however short the strings are.
-// (StringsStruct.Builder.addString copy, StringsStruct.java:120-131.)
+// kStrTileRows rows; the tile's offsets and source offsets are staged in LDS.  Each lane produces one 16-byte aligned
+// chunk of the output body per step: a binary search in the staged offsets finds the row of the chunk's first byte, then
+// every row that overlaps the chunk contributes one unaligned 16-byte load merged under a byte mask.  Stores are
+// full-width and coalesced however short the strings are.  (StringsStruct.Builder.addString, StringsStruct.java:120-131.)
 // ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 ld16u(const uint8_t* p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+// mask of bytes [lo, hi) of a dword, lo/hi clamped to 0..4
+__device__ __forceinline__ uint32_t byte_mask(int lo, int hi) {
+    lo = max(lo, 0);
+    hi = min(hi, 4);
+    if (hi <= lo) return 0u;
+    const uint32_t mh = hi >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u);
+    const uint32_t ml = (1u << (8 * lo)) - 1u;
+    return mh & ~ml;
+}
+
 __global__ __launch_bounds__(256) void k_str_copy(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                   const PackMeta* __restrict__ metas, uint8_t* __restrict__ out,
                                                   const uint8_t* __restrict__ scratch) {
@@ -800,47 +942,56 @@ __global__ __launch_bounds__(256) void k_str_copy(const DevPack* __restrict__ pa
     const uint32_t rows = min((uint32_t)kStrTileRows, n - r0);
     const uint32_t* off = (const uint32_t*)(out + P.out_off);
     uint8_t* body = out + P.out_off + 4ull * (n + 1);
+    // shift all body positions by A so that position 0 is 16-byte aligned in memory
+    const uint32_t A = (uint32_t)((uintptr_t)body & 15);
+    uint8_t* base16 = body - A;
     const uint32_t ec = M.entry_count;
     const uint8_t* dbody = scratch + P.s_dict + 4ull * (ec + 1);
     const uint32_t* srcoff = (const uint32_t*)(scratch + P.s_rows);
 
-    __shared__ uint32_t s_off[kStrTileRows + 1];
-    __shared__ uint32_t s_src[kStrTileRows];
+    __shared__ uint32_t s_off[kStrTileRows + 1];  // shifted output offsets of the tile's rows
+    __shared__ uint32_t s_src[kStrTileRows];      // where each row's bytes start in the dictionary body
     const int tid = threadIdx.x;
-    for (uint32_t i = tid; i <= rows; i += 256) s_off[i] = off[r0 + i];
+    for (uint32_t i = tid; i <= rows; i += 256) s_off[i] = off[r0 + i] + A;
     for (uint32_t i = tid; i < rows; i += 256) s_src[i] = srcoff[r0 + i];
     __syncthreads();
     const uint32_t b0 = s_off[0], b1 = s_off[rows];
     if (b1 <= b0) return;
-    // body + b0 is arbitrary; work on words aligned in the absolute address space of the body
-    const uint32_t w0 = b0 & ~3u;
-    for (uint32_t wpos = w0 + 4 * tid; wpos < b1; wpos += 4 * 256) {
-        // first byte of this word that belongs to the tile
-        const uint32_t first = max(wpos, b0);
-        // binary search: largest r in [0, rows) with s_off[r] <= first
-        uint32_t lo = 0, hi = rows;  // invariant: s_off[lo] <= first < s_off[hi]
+    for (uint32_t cpos = (b0 & ~15u) + 16u * tid; cpos < b1; cpos += 16u * 256u) {
+        const uint32_t first = max(cpos, b0), cend = min(cpos + 16u, b1);
+        // largest r in [0, rows) with s_off[r] <= first      (invariant: s_off[lo] <= first < s_off[hi])
+        uint32_t lo = 0, hi = rows;
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
             if (s_off[mid] <= first) lo = mid; else hi = mid;
         }
         uint32_t r = lo;
-        uint32_t rend = s_off[r + 1];
-        uint32_t delta = s_src[r] - s_off[r];  // source = dbody + pos + delta (mod 2^32)
-        uint32_t word = 0;
-        uint32_t mask = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t pos = wpos + k;
-            if (pos >= b0 && pos < b1) {
-                while (pos >= rend) { r++; rend = s_off[r + 1]; delta = s_src[r] - s_off[r]; }
-                word |= (uint32_t)dbody[pos + delta] << (8 * k);
-                mask |= 0xFFu << (8 * k);
-            }
+        uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+        uint32_t pos = first;
+        while (pos < cend) {
+            uint32_t rend = s_off[r + 1];
+            while (rend <= pos) { r++; rend = s_off[r + 1]; }  // skip rows that end here (empty rows)
+            const uint32_t segend = min(cend, rend);
+            // chunk byte k comes from dbody[s_src[r] + (cpos + k - s_off[r])]
+            const int64_t so = (int64_t)s_src[r] + (int64_t)cpos - (int64_t)s_off[r];
+            const uint4 v = ld16u(dbody + so);
+            const int a = (int)(pos - cpos), e = (int)(segend - cpos);
+            const uint32_t m0 = byte_mask(a, e), m1 = byte_mask(a - 4, e - 4), m2 = byte_mask(a - 8, e - 8), m3 = byte_mask(a - 12, e - 12);
+            w0 = (w0 & ~m0) | (v.x & m0);
+            w1 = (w1 & ~m1) | (v.y & m1);
+            w2 = (w2 & ~m2) | (v.z & m2);
+            w3 = (w3 & ~m3) | (v.w & m3);
+            pos = segend;
         }
-        if (mask == 0xFFFFFFFFu) *(uint32_t*)(body + wpos) = word;
-        else {
+        if (first == cpos && cend == cpos + 16u) {
+            *(uint4*)(base16 + cpos) = make_uint4(w0, w1, w2, w3);
+        } else {
+            const uint32_t w[4] = {w0, w1, w2, w3};
 #pragma unroll
-            for (int k = 0; k < 4; k++) if (mask & (0xFFu << (8 * k))) body[wpos + k] = (uint8_t)(word >> (8 * k));
+            for (int k = 0; k < 16; k++) {
+                const uint32_t q = cpos + k;
+                if (q >= first && q < cend) base16[q] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+            }
         }
     }
 }
@@ -916,6 +1067,7 @@ __global__ void k_ds_meta(const DevPack* __restrict__ packs, const int* __restri
     PackMeta m;
     m.status = P.pack_size; m.kind = P.width ? K_DICT_NUM : K_DICT_STR; m.entry_count = 0; m.id_bw = 0; m.ids_off = 0;
     m.ids_len = 0; m.entries_off = 4; m.entries_plain = 1; m.sfx_off = 0; m.sfx_len = 0; m.dict_struct_size = psz; m.max_len = 0;
+    m.front_blocks = 0; m.front_stride = 0;
     m.s[0].n = m.s[1].n = 0; m.s[0].in_off = m.s[1].in_off = 0; m.s[0].first = m.s[1].first = 0;
     int32_t err = 0;
     if (psz < 8 || n == 0 || n > 65536u) err = E_CORRUPT;
@@ -1032,9 +1184,21 @@ void launch_str_dict_scan(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;
     hipLaunchKernelGGL(k_str_dict_scan, dim3(count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
 }
-void launch_front_decode(const LaunchCtx& c, const int* list, int count) {
+void launch_front_serial(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_front_decode, dim3(4, count), dim3(64), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+    hipLaunchKernelGGL(k_front_serial, dim3(4, count), dim3(64), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+}
+void launch_front_summary(const LaunchCtx& c, const int* list, int count, int use_ds) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_front_summary, dim3(32, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch, use_ds);
+}
+void launch_front_combine(const LaunchCtx& c, const int* list, int count, int use_ds) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_front_combine, dim3(4, count), dim3(64), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch, use_ds);
+}
+void launch_front_decode(const LaunchCtx& c, const int* list, int count, int use_ds) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_front_decode, dim3(32, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch, use_ds);
 }
 void launch_str_rows(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;

@@ -25,7 +25,10 @@ void launch_delta(const LaunchCtx& c, const int* list, int count, int width, int
 void launch_dict_num(const LaunchCtx& c, const int* list, int count, int width);
 void launch_copy_raw(const LaunchCtx& c, const int* list, int count);
 void launch_str_dict_scan(const LaunchCtx& c, const int* list, int count);
-void launch_front_decode(const LaunchCtx& c, const int* list, int count);
+void launch_front_serial(const LaunchCtx& c, const int* list, int count);
+void launch_front_summary(const LaunchCtx& c, const int* list, int count, int use_ds);
+void launch_front_combine(const LaunchCtx& c, const int* list, int count, int use_ds);
+void launch_front_decode(const LaunchCtx& c, const int* list, int count, int use_ds);
 void launch_str_rows(const LaunchCtx& c, const int* list, int count);
 void launch_row_scan(const LaunchCtx& c, const int* list, int count);
 void launch_str_copy(const LaunchCtx& c, const int* list, int count);
