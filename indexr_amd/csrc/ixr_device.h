@@ -9,7 +9,10 @@ namespace ixr {
 constexpr int kBlock = 128;        // values per delta block (one zig-zag varint minDelta each)
 constexpr int kMini = 32;          // values per mini-block (one width byte each)
 constexpr int kRleTile = 1024;     // rows per RLE restart point / per wave tile in the id-expanding kernels
-constexpr int kStrTileRows = 256;  // rows per workgroup tile in the string body copy
+#ifndef IXR_STR_TILE_ROWS
+#define IXR_STR_TILE_ROWS 256
+#endif
+constexpr int kStrTileRows = IXR_STR_TILE_ROWS;  // rows per workgroup tile in the string body copy
 constexpr int kFrontBlock = 64;    // strings per block of the parallel front-coding decode
 
 // Element stride of the per-pack string length arrays (prefixLen / suffixLen / sufOff): obj_count rounded up to 4 so that

@@ -385,9 +385,10 @@ __global__ __launch_bounds__(256) void k_delta(const DevPack* __restrict__ packs
     __shared__ U wsum[2][4];
     U carry = (U)s.first;
     int buf = 0;
-    for (uint32_t c0 = 0; c0 < n; c0 += 1024, buf ^= 1) {
+    // unpack the 4 values of this thread for the chunk starting at c0 (minDelta already added); zeros past the end
+    auto unpack4 = [&](uint32_t c0, U& d0, U& d1, U& d2, U& d3) {
         const uint32_t i0 = c0 + 4 * tid;
-        U d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+        d0 = d1 = d2 = d3 = 0;
         if (i0 < n) {
             const uint32_t hdr = mb[i0 >> 5];
             const uint32_t bw = hdr >> 24;
@@ -399,6 +400,14 @@ __global__ __launch_bounds__(256) void k_delta(const DevPack* __restrict__ packs
             if (i0 + 2 < n) d2 = extract<U>(src, bit + 2 * bw, bw) + md;
             if (i0 + 3 < n) d3 = extract<U>(src, bit + 3 * bw, bw) + md;
         }
+    };
+    U d0, d1, d2, d3;
+    unpack4(0, d0, d1, d2, d3);
+    for (uint32_t c0 = 0; c0 < n; c0 += 1024, buf ^= 1) {
+        const uint32_t i0 = c0 + 4 * tid;
+        // software pipeline: the next chunk's loads are issued before this chunk's scan and barrier
+        U e0, e1, e2, e3;
+        unpack4(c0 + 1024, e0, e1, e2, e3);
         d1 += d0; d2 += d1; d3 += d2;
         const U incl = wave_incl_scan<U>(d3);
         if (lane == 63) wsum[buf][wave] = incl;
@@ -423,26 +432,44 @@ __global__ __launch_bounds__(256) void k_delta(const DevPack* __restrict__ packs
             if (i0 + 2 < n) dst[i0 + 2] = d2 + pre;
         }
         carry += w0 + w1 + w2 + w3;
+        d0 = e0; d1 = e1; d2 = e2; d3 = e3;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// RLE tile iteration shared by the id-consuming kernels: a wave walks the segments that overlap its tile, starting
-// from the restart point the parse kernel left, and hands every (row, id) of the tile to `f`, 64 rows at a time.
+// XCD-aware block relabelling for (blocks-per-pack, packs) grids.  Workgroups are dealt round-robin over the 8 XCDs by
+// linear id, which spreads the blocks of one pack -- and with them its dictionary -- over all 8 L2s.  Relabel so that all
+// blocks of a pack have linear ids that are equal mod 8: one pack, one L2.  Placement only affects speed.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename F>
-__device__ __forceinline__ void rle_tile_foreach(const uint8_t* base, const PackMeta& M, uint2 restart, uint32_t tile_start,
-                                                 uint32_t tile_end, F f) {
+__device__ __forceinline__ void pack_block_remap(uint32_t& bx, uint32_t& by) {
+    const uint32_t gx = gridDim.x, count = gridDim.y;
+    const uint32_t L = blockIdx.y * gx + blockIdx.x;
+    const uint32_t full = count & ~7u;
+    if (L < full * gx) {
+        const uint32_t xcd = L & 7u, sidx = L >> 3;
+        by = (sidx / gx) * 8u + xcd;
+        bx = sidx % gx;
+    } else {
+        by = blockIdx.y;
+        bx = blockIdx.x;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// RLE tile expansion shared by the id-consuming kernels: a wave walks the segments that overlap its tile of kRleTile rows,
+// starting from the restart point the parse kernel left, and writes the tile's ids (always < 65536) into LDS.  The
+// consumers then read them back 16 rows per lane, which lets them keep 16 independent gathers in flight.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rle_tile_expand(const uint8_t* base, uint32_t bw, uint32_t ids_end, uint2 restart,
+                                                uint32_t tile_start, uint32_t tile_end, uint16_t* ids) {
     const int lane = threadIdx.x & 63;
-    const uint32_t bw = M.id_bw;
     const uint32_t bytew = (bw + 7) >> 3;
-    const uint32_t end = M.ids_off + 4 + M.ids_len;
     uint32_t pos = restart.x, o = restart.y;
-    while (o < tile_end && pos < end) {
+    while (o < tile_end && pos < ids_end) {
         // uniform header parse (every lane reads the same bytes)
         uint32_t h = 0;
         int shift = 0;
-        for (int i = 0; i < 5 && pos < end; i++) {
+        for (int i = 0; i < 5 && pos < ids_end; i++) {
             uint32_t b = base[pos++];
             h |= (b & 0x7F) << shift;
             if (!(b & 0x80)) break;
@@ -452,16 +479,42 @@ __device__ __forceinline__ void rle_tile_foreach(const uint8_t* base, const Pack
         const uint32_t lo = max(o, tile_start), hi = min(o + cnt, tile_end);
         if (h & 1) {
             const uint8_t* data = base + pos;
-            for (uint32_t i = lo + lane; i < hi; i += 64) f(i, extract32(data, (i - o) * bw, bw));
+#pragma unroll 4
+            for (uint32_t i = lo + lane; i < hi; i += 64) ids[i - tile_start] = (uint16_t)extract32(data, (i - o) * bw, bw);
             pos += ((cnt + 7) >> 3) * bw;
         } else {
             uint32_t val = 0;
             for (uint32_t b = 0; b < bytew; b++) val |= (uint32_t)base[pos + b] << (8 * b);
-            for (uint32_t i = lo + lane; i < hi; i += 64) f(i, val);
+            for (uint32_t i = lo + lane; i < hi; i += 64) ids[i - tile_start] = (uint16_t)val;
             pos += bytew;
         }
         o += cnt;
     }
+    // the tile's ids were written by this wave only; make them visible to all its lanes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Common prologue of the tile kernels: which pack / tile this wave owns. Returns false when there is nothing to do.
+struct TileCtx {
+    int pi;
+    uint32_t n, tile, tile_start, tile_end, ec;
+};
+__device__ __forceinline__ bool tile_ctx(TileCtx& t, const DevPack* packs, const int* list, const PackMeta* metas, int kind,
+                                         uint32_t first_tile_block) {
+    uint32_t bx, by;
+    pack_block_remap(bx, by);
+    t.pi = list[by];
+    const PackMeta& M = metas[t.pi];
+    if (M.status < 0 || M.kind != kind || bx < first_tile_block) return false;
+    t.n = (uint32_t)packs[t.pi].obj_count;
+    t.tile = (bx - first_tile_block) * 4 + (threadIdx.x >> 6);
+    t.tile_start = t.tile * kRleTile;
+    if (t.tile_start >= t.n) return false;
+    t.tile_end = min(t.n, t.tile_start + (uint32_t)kRleTile);
+    t.ec = M.entry_count;
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -472,26 +525,35 @@ template <typename U>
 __global__ __launch_bounds__(256) void k_dict_num(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                   PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                   uint8_t* __restrict__ out, const uint8_t* __restrict__ scratch) {
-    const int pi = list[blockIdx.y];
-    const PackMeta& M = metas[pi];
-    if (M.status < 0 || M.kind != K_DICT_NUM) return;
-    const DevPack P = packs[pi];
-    const uint32_t n = (uint32_t)P.obj_count;
-    const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint32_t tile_start = tile * kRleTile;
-    if (tile_start >= n) return;
-    const uint32_t tile_end = min(n, tile_start + (uint32_t)kRleTile);
+    __shared__ uint16_t s_ids[4][kRleTile];
+    TileCtx t;
+    if (!tile_ctx(t, packs, list, metas, K_DICT_NUM, 0)) return;
+    const DevPack& P = packs[t.pi];
+    const PackMeta& M = metas[t.pi];
     const uint8_t* base = in + P.in_off;
-    const U* dict = (const U*)(scratch + P.s_dict);
-    U* dst = (U*)(out + P.out_off);
-    const uint32_t ec = M.entry_count;
-    const uint2 restart = ((const uint2*)(scratch + P.s_restart))[tile];
+    const U* __restrict__ dict = (const U*)(scratch + P.s_dict);
+    U* __restrict__ dst = (U*)(out + P.out_off) + t.tile_start;
+    uint16_t* ids = s_ids[threadIdx.x >> 6];
+    const uint2 restart = ((const uint2*)(scratch + P.s_restart))[t.tile];
+    rle_tile_expand(base, M.id_bw, M.ids_off + 4 + M.ids_len, restart, t.tile_start, t.tile_end, ids);
+    const uint32_t cnt = t.tile_end - t.tile_start, lane = threadIdx.x & 63;
+    uint32_t id[16];
     bool bad = false;
-    rle_tile_foreach(base, M, restart, tile_start, tile_end, [&](uint32_t i, uint32_t id) {
-        if (id >= ec) { bad = true; id = 0; }
-        dst[i] = dict[id];
-    });
-    if (bad) metas[pi].status = E_CORRUPT;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const uint32_t r = q * 64 + lane;
+        id[q] = r < cnt ? ids[r] : 0u;
+        if (id[q] >= t.ec) { bad = true; id[q] = 0; }
+    }
+    U v[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) v[q] = dict[id[q]];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const uint32_t r = q * 64 + lane;
+        if (r < cnt) dst[r] = v[q];
+    }
+    if (bad) metas[t.pi].status = E_CORRUPT;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -820,17 +882,24 @@ __global__ __launch_bounds__(256) void k_front_decode(const DevPack* __restrict_
         for (uint32_t col0 = 0; col0 < f.stride; col0 += 64) {
             const uint32_t j = col0 + lane;
             uint32_t cur = f.sum[(size_t)b * f.stride + j];
-#pragma unroll 4
-            for (uint32_t k = 0; k < cnt; k++) {
-                const uint32_t p = __builtin_amdgcn_readlane(mp, k), sl = __builtin_amdgcn_readlane(ms, k);
-                const uint32_t len = p + sl;
-                if (len <= col0) continue;  // uniform
-                const uint32_t o = __builtin_amdgcn_readlane(mo, k), so = __builtin_amdgcn_readlane(mso, k);
-                const bool in_suffix = j >= p && j < len;
-                // unconditional, clamped load (so + 0 is always readable: suffix bytes are followed by the id stream)
-                const uint32_t t = f.sfx[so + (in_suffix ? j - p : 0u)];
-                cur = in_suffix ? t : cur;
-                if (j < len) f.body[o + j] = (uint8_t)cur;
+            for (uint32_t k0 = 0; k0 < cnt; k0 += 8) {
+                // 8 strings per step: all suffix loads are issued before the first byte is consumed
+                uint32_t p[8], len[8], o[8], t[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const uint32_t k = min(k0 + q, cnt - 1);
+                    p[q] = __builtin_amdgcn_readlane(mp, k);
+                    len[q] = k0 + q < cnt ? p[q] + __builtin_amdgcn_readlane(ms, k) : 0u;  // len 0: no column takes part
+                    o[q] = __builtin_amdgcn_readlane(mo, k);
+                    const uint32_t so = __builtin_amdgcn_readlane(mso, k);
+                    // unconditional, clamped load (so + 0 is always readable: suffix bytes are followed by the id stream)
+                    t[q] = f.sfx[so + ((j >= p[q] && j < len[q]) ? j - p[q] : 0u)];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    cur = (j >= p[q] && j < len[q]) ? t[q] : cur;
+                    if (j < len[q]) f.body[o[q] + j] = (uint8_t)cur;
+                }
             }
         }
     }
@@ -844,29 +913,36 @@ __global__ __launch_bounds__(256) void k_front_decode(const DevPack* __restrict_
 __global__ __launch_bounds__(256) void k_str_rows(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                   PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                   uint8_t* __restrict__ out, uint8_t* __restrict__ scratch) {
-    const int pi = list[blockIdx.y];
-    const PackMeta& M = metas[pi];
-    if (M.status < 0 || M.kind != K_DICT_STR) return;
-    const DevPack P = packs[pi];
-    const uint32_t n = (uint32_t)P.obj_count;
-    const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint32_t tile_start = tile * kRleTile;
-    if (tile_start >= n) return;
-    const uint32_t tile_end = min(n, tile_start + (uint32_t)kRleTile);
+    __shared__ uint16_t s_ids[4][kRleTile];
+    TileCtx t;
+    if (!tile_ctx(t, packs, list, metas, K_DICT_STR, 0)) return;
+    const DevPack& P = packs[t.pi];
+    const PackMeta& M = metas[t.pi];
     const uint8_t* base = in + P.in_off;
-    const uint32_t* doff = (const uint32_t*)(scratch + P.s_dict);
-    uint32_t* rowlen = (uint32_t*)(out + P.out_off) + 1;
-    uint32_t* srcoff = (uint32_t*)(scratch + P.s_rows);
-    const uint32_t ec = M.entry_count;
-    const uint2 restart = ((const uint2*)(scratch + P.s_restart))[tile];
+    const uint32_t* __restrict__ doff = (const uint32_t*)(scratch + P.s_dict);
+    uint32_t* __restrict__ rowlen = (uint32_t*)(out + P.out_off) + 1 + t.tile_start;
+    uint32_t* __restrict__ srcoff = (uint32_t*)(scratch + P.s_rows) + t.tile_start;
+    uint16_t* ids = s_ids[threadIdx.x >> 6];
+    const uint2 restart = ((const uint2*)(scratch + P.s_restart))[t.tile];
+    rle_tile_expand(base, M.id_bw, M.ids_off + 4 + M.ids_len, restart, t.tile_start, t.tile_end, ids);
+    const uint32_t cnt = t.tile_end - t.tile_start, lane = threadIdx.x & 63;
+    uint32_t id[16];
     bool bad = false;
-    rle_tile_foreach(base, M, restart, tile_start, tile_end, [&](uint32_t i, uint32_t id) {
-        if (id >= ec) { bad = true; id = 0; }
-        const uint32_t a = doff[id], b = doff[id + 1];
-        rowlen[i] = b - a;
-        srcoff[i] = a;
-    });
-    if (bad) metas[pi].status = E_CORRUPT;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const uint32_t r = q * 64 + lane;
+        id[q] = r < cnt ? ids[r] : 0u;
+        if (id[q] >= t.ec) { bad = true; id[q] = 0; }
+    }
+    uint2 ab[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) __builtin_memcpy(&ab[q], doff + id[q], 8);  // doff[id], doff[id + 1]
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const uint32_t r = q * 64 + lane;
+        if (r < cnt) { rowlen[r] = ab[q].y - ab[q].x; srcoff[r] = ab[q].x; }
+    }
+    if (bad) metas[t.pi].status = E_CORRUPT;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -909,35 +985,33 @@ __global__ __launch_bounds__(256) void k_row_scan(const DevPack* __restrict__ pa
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_str_copy: string dictionary packs: body[offset[i] .. offset[i+1]) = dictBody[srcOff[i] ..].  One workgroup per tile of
-// kStrTileRows rows; the tile's offsets and source offsets are staged in LDS.  Each lane produces one 16-byte aligned
-// chunk of the output body per step: a binary search in the staged offsets finds the row of the chunk's first byte, then
-// every row that overlaps the chunk contributes one unaligned 16-byte load merged under a byte mask.  Stores are
-// full-width and coalesced however short the strings are.  (StringsStruct.Builder.addString, StringsStruct.java:120-131.)
+// kStrTileRows rows; the tile's offsets are staged in LDS.  Each lane produces 16-byte aligned chunks of the output body:
+// a branch-free binary search in the staged offsets finds the row of the chunk's first byte, then every row that
+// overlaps the chunk contributes one unaligned 16-byte load merged under a byte mask.  Stores are full-width and
+// coalesced however short the strings are.  (StringsStruct.Builder.addString, StringsStruct.java:120-131.)
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint4 ld16u(const uint8_t* p) {
     uint4 v;
     __builtin_memcpy(&v, p, 16);
     return v;
 }
-// mask of bytes [lo, hi) of a dword, lo/hi clamped to 0..4
-__device__ __forceinline__ uint32_t byte_mask(int lo, int hi) {
-    lo = max(lo, 0);
-    hi = min(hi, 4);
-    if (hi <= lo) return 0u;
-    const uint32_t mh = hi >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u);
-    const uint32_t ml = (1u << (8 * lo)) - 1u;
-    return mh & ~ml;
+// 64-bit mask with the low 8*x bits set, x clamped to 0..8
+__device__ __forceinline__ uint64_t low_bytes(int x) {
+    x = max(x, 0);
+    return x >= 8 ? ~0ull : ((1ull << (8 * x)) - 1ull);
 }
 
 __global__ __launch_bounds__(256) void k_str_copy(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                   const PackMeta* __restrict__ metas, uint8_t* __restrict__ out,
                                                   const uint8_t* __restrict__ scratch) {
-    const int pi = list[blockIdx.y];
+    uint32_t bx, by;
+    pack_block_remap(bx, by);
+    const int pi = list[by];
     const PackMeta& M = metas[pi];
     if (M.status < 0 || M.kind != K_DICT_STR) return;
-    const DevPack P = packs[pi];
+    const DevPack& P = packs[pi];
     const uint32_t n = (uint32_t)P.obj_count;
-    const uint32_t r0 = blockIdx.x * kStrTileRows;
+    const uint32_t r0 = bx * kStrTileRows;
     if (r0 >= n) return;
     const uint32_t rows = min((uint32_t)kStrTileRows, n - r0);
     const uint32_t* off = (const uint32_t*)(out + P.out_off);
@@ -950,49 +1024,77 @@ __global__ __launch_bounds__(256) void k_str_copy(const DevPack* __restrict__ pa
     const uint32_t* srcoff = (const uint32_t*)(scratch + P.s_rows);
 
     __shared__ uint32_t s_off[kStrTileRows + 1];  // shifted output offsets of the tile's rows
-    __shared__ uint32_t s_src[kStrTileRows];      // where each row's bytes start in the dictionary body
+    __shared__ uint32_t s_dlt[kStrTileRows];      // srcOff - s_off + 16 (mod 2^32): source position = s_dlt + output position
     const int tid = threadIdx.x;
     for (uint32_t i = tid; i <= rows; i += 256) s_off[i] = off[r0 + i] + A;
-    for (uint32_t i = tid; i < rows; i += 256) s_src[i] = srcoff[r0 + i];
+    for (uint32_t i = tid; i < rows; i += 256) s_dlt[i] = srcoff[r0 + i] - (off[r0 + i] + A) + 16u;
     __syncthreads();
     const uint32_t b0 = s_off[0], b1 = s_off[rows];
     if (b1 <= b0) return;
-    for (uint32_t cpos = (b0 & ~15u) + 16u * tid; cpos < b1; cpos += 16u * 256u) {
-        const uint32_t first = max(cpos, b0), cend = min(cpos + 16u, b1);
-        // largest r in [0, rows) with s_off[r] <= first      (invariant: s_off[lo] <= first < s_off[hi])
-        uint32_t lo = 0, hi = rows;
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (s_off[mid] <= first) lo = mid; else hi = mid;
+    const uint8_t* dbody16 = dbody - 16;  // chunk byte k of row r comes from dbody16[s_dlt[r] + cpos + k]; the sum is >= 1
+
+#ifdef IXR_ABL_NOLOAD
+#define IXR_LD16(p, c) make_uint4((uint32_t)(uintptr_t)(p), c, c, c)
+#else
+#define IXR_LD16(p, c) ld16u(p)
+#endif
+    // One 16-byte chunk: finish it given the row `r` of its first byte; handles chunks that straddle rows.
+    auto finish = [&](uint32_t cpos, uint32_t first, uint32_t cend, uint32_t r, uint4 w) {
+        uint32_t rend = s_off[r + 1];
+        uint32_t pos = min(cend, rend);
+#ifndef IXR_ABL_NOSTRADDLE
+        if (pos < cend) {
+            uint64_t wl = (uint64_t)w.x | ((uint64_t)w.y << 32), wh = (uint64_t)w.z | ((uint64_t)w.w << 32);
+            while (pos < cend) {
+                do { r++; rend = s_off[r + 1]; } while (rend <= pos && r + 1 < rows);  // next row that is not empty
+                const uint32_t segend = min(cend, max(rend, pos + 1));
+                const uint4 v = IXR_LD16(dbody16 + (uint32_t)(s_dlt[r] + cpos), cpos);
+                const int a = (int)(pos - cpos), e = (int)(segend - cpos);
+                const uint64_t ml = low_bytes(e) & ~low_bytes(a), mh = low_bytes(e - 8) & ~low_bytes(a - 8);
+                wl = (wl & ~ml) | (((uint64_t)v.x | ((uint64_t)v.y << 32)) & ml);
+                wh = (wh & ~mh) | (((uint64_t)v.z | ((uint64_t)v.w << 32)) & mh);
+                pos = segend;
+            }
+            w = make_uint4((uint32_t)wl, (uint32_t)(wl >> 32), (uint32_t)wh, (uint32_t)(wh >> 32));
         }
-        uint32_t r = lo;
-        uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-        uint32_t pos = first;
-        while (pos < cend) {
-            uint32_t rend = s_off[r + 1];
-            while (rend <= pos) { r++; rend = s_off[r + 1]; }  // skip rows that end here (empty rows)
-            const uint32_t segend = min(cend, rend);
-            // chunk byte k comes from dbody[s_src[r] + (cpos + k - s_off[r])]
-            const int64_t so = (int64_t)s_src[r] + (int64_t)cpos - (int64_t)s_off[r];
-            const uint4 v = ld16u(dbody + so);
-            const int a = (int)(pos - cpos), e = (int)(segend - cpos);
-            const uint32_t m0 = byte_mask(a, e), m1 = byte_mask(a - 4, e - 4), m2 = byte_mask(a - 8, e - 8), m3 = byte_mask(a - 12, e - 12);
-            w0 = (w0 & ~m0) | (v.x & m0);
-            w1 = (w1 & ~m1) | (v.y & m1);
-            w2 = (w2 & ~m2) | (v.z & m2);
-            w3 = (w3 & ~m3) | (v.w & m3);
-            pos = segend;
-        }
+#endif
         if (first == cpos && cend == cpos + 16u) {
-            *(uint4*)(base16 + cpos) = make_uint4(w0, w1, w2, w3);
+            *(uint4*)(base16 + cpos) = w;
         } else {
-            const uint32_t w[4] = {w0, w1, w2, w3};
+            const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const uint32_t q = cpos + k;
-                if (q >= first && q < cend) base16[q] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+                if (q >= first && q < cend) base16[q] = (uint8_t)(wv[k >> 2] >> (8 * (k & 3)));
             }
         }
+    };
+
+    // Two chunks per lane and step (4 KiB apart, so that each store instruction of the wave stays contiguous): the two
+    // row searches run in one branch-free loop and both first loads are in flight together.
+    for (uint32_t cA = (b0 & ~15u) + 16u * tid; cA < b1; cA += 2u * 16u * 256u) {
+        const uint32_t cB = cA + 16u * 256u;
+        const bool hasB = cB < b1;
+        const uint32_t fA = max(cA, b0), eA = min(cA + 16u, b1);
+        const uint32_t fB = hasB ? cB : fA, eB = min(cB + 16u, b1);
+        // largest r in [0, rows) with s_off[r] <= first: s_off[0] = b0 <= first < b1 = s_off[rows]
+        uint32_t rA = 0, rB = 0;
+#ifdef IXR_ABL_NOSEARCH
+        rA = min(rows - 1, (uint32_t)(((uint64_t)(fA - b0) * rows) / (b1 - b0)));
+        rB = min(rows - 1, (uint32_t)(((uint64_t)(fB - b0) * rows) / (b1 - b0)));
+#else
+#pragma unroll
+        for (uint32_t step = kStrTileRows / 2; step >= 1; step >>= 1) {
+            const uint32_t ca = rA + step, cb = rB + step;
+            const uint32_t oa = s_off[min(ca, (uint32_t)kStrTileRows)], ob = s_off[min(cb, (uint32_t)kStrTileRows)];
+            if (ca < rows && oa <= fA) rA = ca;
+            if (cb < rows && ob <= fB) rB = cb;
+        }
+#endif
+        const uint4 wA = IXR_LD16(dbody16 + (uint32_t)(s_dlt[rA] + cA), cA);
+        const uint4 wB = IXR_LD16(dbody16 + (uint32_t)(s_dlt[rB] + (hasB ? cB : cA)), cB);
+        finish(cA, fA, eA, rA, wA);
+        if (hasB) finish(cB, fB, eB, rB, wB);
     }
 }
 
@@ -1005,6 +1107,7 @@ __global__ __launch_bounds__(256) void k_str_copy(const DevPack* __restrict__ pa
 __global__ __launch_bounds__(256) void k_dict_struct(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                      PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                      uint8_t* __restrict__ out, const uint8_t* __restrict__ scratch) {
+    __shared__ uint16_t s_ids[4][kRleTile];
     const int pi = list[blockIdx.y];
     const PackMeta& M = metas[pi];
     if (M.status < 0 || (M.kind != K_DICT_NUM && M.kind != K_DICT_STR) || M.dict_struct_size == 0) return;
@@ -1037,16 +1140,20 @@ __global__ __launch_bounds__(256) void k_dict_struct(const DevPack* __restrict__
     const uint32_t tile_start = tile * kRleTile;
     if (tile_start >= n) return;
     const uint32_t tile_end = min(n, tile_start + (uint32_t)kRleTile);
-    uint8_t* ids = ds + 4 + dict_size + 4;
-    const bool aligned = (((uintptr_t)ids) & 3) == 0;
+    uint8_t* idp = ds + 4 + dict_size + 4 + 4ull * tile_start;
+    const bool aligned = (((uintptr_t)idp) & 3) == 0;
     const uint2 restart = ((const uint2*)(scratch + P.s_restart))[tile];
-    rle_tile_foreach(in + P.in_off, M, restart, tile_start, tile_end, [&](uint32_t i, uint32_t id) {
-        if (aligned) ((uint32_t*)ids)[i] = id;
+    uint16_t* ids = s_ids[threadIdx.x >> 6];
+    rle_tile_expand(in + P.in_off, M.id_bw, M.ids_off + 4 + M.ids_len, restart, tile_start, tile_end, ids);
+    const uint32_t cnt = tile_end - tile_start;
+    for (uint32_t r = threadIdx.x & 63; r < cnt; r += 64) {
+        const uint32_t id = ids[r];
+        if (aligned) ((uint32_t*)idp)[r] = id;
         else {
-            uint8_t* p = ids + 4ull * i;
-            p[0] = (uint8_t)id; p[1] = (uint8_t)(id >> 8); p[2] = (uint8_t)(id >> 16); p[3] = (uint8_t)(id >> 24);
+            uint8_t* p = idp + 4ull * r;
+            p[0] = (uint8_t)id; p[1] = (uint8_t)(id >> 8); p[2] = 0; p[3] = 0;
         }
-    });
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1198,7 +1305,7 @@ void launch_front_combine(const LaunchCtx& c, const int* list, int count, int us
 }
 void launch_front_decode(const LaunchCtx& c, const int* list, int count, int use_ds) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_front_decode, dim3(32, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch, use_ds);
+    hipLaunchKernelGGL(k_front_decode, dim3(64, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch, use_ds);
 }
 void launch_str_rows(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;

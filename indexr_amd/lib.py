@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libixrgpu.so")
+LIB_PATH = os.environ.get("IXR_LIB") or os.path.join(_HERE, "libixrgpu.so")  # IXR_LIB: A/B builds of the same library
 
 INT, LONG, FLOAT, DOUBLE, STRING = 1, 2, 3, 4, 5
 ENC_RAW, ENC_DELTA, ENC_SIMPLE_DICT, ENC_DICT_COMPRESS = 0, 2, 4, 6
