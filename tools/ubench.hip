@@ -76,6 +76,18 @@ int main() {
     timeit("copy16 grid 2048", [&] { hipLaunchKernelGGL(copy16, dim3(2048), dim3(256), 0, 0, a, b, nvec); }, 2 * 4.295);
     timeit("copy16 grid 16384", [&] { hipLaunchKernelGGL(copy16, dim3(16384), dim3(256), 0, 0, a, b, nvec); }, 2 * 4.295);
     timeit("gather16 unaligned (out GB/s)", [&] { hipLaunchKernelGGL(gather16u, dim3(nblocks), dim3(256), 0, 0, dict, drp, a, vec_per_block, dict_bytes); }, nblocks * vec_per_block * 16 / 1e9);
+    // the same gathers when every block reads ONE 900 KB dictionary (resident in every XCD's L2)
+    std::vector<uint32_t> rp1(rp.size());
+    for (size_t i = 0; i < rp1.size(); i++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; rp1[i] = (uint32_t)(x % (dict_bytes - 64)); }
+    uint32_t* drp1; CK(hipMalloc(&drp1, rp1.size() * 4)); CK(hipMemcpy(drp1, rp1.data(), rp1.size() * 4, hipMemcpyHostToDevice));
+    timeit("gather16 unaligned, L2 dict", [&] { hipLaunchKernelGGL(gather16u, dim3(nblocks), dim3(256), 0, 0, dict, drp1, a, vec_per_block, dict_bytes); }, nblocks * vec_per_block * 16 / 1e9);
+    // aligned variant of the same: rows at multiples of 16
+    for (auto& v : rp1) v &= ~15u;
+    CK(hipMemcpy(drp1, rp1.data(), rp1.size() * 4, hipMemcpyHostToDevice));
+    timeit("gather16 aligned rows, L2 dict", [&] { hipLaunchKernelGGL(gather16u, dim3(nblocks), dim3(256), 0, 0, dict, drp1, a, vec_per_block, dict_bytes); }, nblocks * vec_per_block * 16 / 1e9);
+    for (auto& v : rp) v &= ~15u;
+    CK(hipMemcpy(drp, rp.data(), rp.size() * 4, hipMemcpyHostToDevice));
+    timeit("gather16 aligned rows, 512 dicts", [&] { hipLaunchKernelGGL(gather16u, dim3(nblocks), dim3(256), 0, 0, dict, drp, a, vec_per_block, dict_bytes); }, nblocks * vec_per_block * 16 / 1e9);
     timeit("gather16 2xaligned (out GB/s)", [&] { hipLaunchKernelGGL(gather16a, dim3(nblocks), dim3(256), 0, 0, dict, drp, a, vec_per_block, dict_bytes); }, nblocks * vec_per_block * 16 / 1e9);
     return 0;
 }
