@@ -40,6 +40,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU")
     ap.add_argument("--workload", default="mixed", choices=sorted(WORKLOADS))
+    ap.add_argument("--kinds", default="", help="comma-separated synthetic column kinds (kernel experiments; overrides --workload)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xC0FFEE)
     ap.add_argument("--threads", type=int, default=0, help="host threads for input synthesis / CPU baseline")
     ap.add_argument("--scratch-gib", type=float, default=8.0)
@@ -73,6 +74,9 @@ def main():
     if threads == 1 and not args.threads:
         threads = 16  # torchrun exports OMP_NUM_THREADS=1 when it is unset
     desc_text, kinds = WORKLOADS[args.workload]
+    if args.kinds:
+        kinds = [int(k) for k in args.kinds.split(",")]
+        desc_text = "experiment: synthetic column kinds %s" % kinds
     rows = args.rows
     n_packs = (rows + 65535) >> 16  # DataPack.rowCountToPackCount (DataPack.java:773-803)
     last_rows = rows - (n_packs - 1) * 65536

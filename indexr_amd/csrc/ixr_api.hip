@@ -270,7 +270,7 @@ static ixr_plan* plan_create(int32_t device, const ixr_pack_desc* descs, int32_t
     if ((e = hipMalloc((void**)&pl->d_packs, sizeof(DevPack) * (size_t)n_packs)) != hipSuccess ||
         (e = hipMalloc((void**)&pl->d_metas, sizeof(PackMeta) * (size_t)n_packs)) != hipSuccess ||
         (e = hipMalloc((void**)&pl->d_lists, sizeof(int) * std::max<size_t>(lists.size(), 1))) != hipSuccess ||
-        (e = hipMalloc((void**)&pl->d_scratch, std::max<uint64_t>(pl->scratch_bytes, 16))) != hipSuccess) {
+        (e = hipMalloc((void**)&pl->d_scratch, pl->scratch_bytes + 256)) != hipSuccess) {
         fail(IXR_ERR_OUT_OF_MEMORY, "hipMalloc for the plan failed: %s", hipGetErrorString(e));
         ixr_plan_destroy(pl);
         return nullptr;

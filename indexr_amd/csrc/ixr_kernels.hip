@@ -759,8 +759,10 @@ struct FrontCtx {
     uint16_t* sum;
 };
 
+// `ro` is the scratch base again, as a read-only view: the length / offset arrays read through it are never written by
+// the kernels that use it, which lets the compiler fetch wave-uniform entries with scalar loads.
 __device__ __forceinline__ bool front_ctx(FrontCtx& f, const DevPack& P, const PackMeta& M, const uint8_t* in, uint8_t* out,
-                                          uint8_t* scratch, int use_ds, bool parallel) {
+                                          uint8_t* scratch, const uint8_t* ro, int use_ds, bool parallel) {
     if (M.status < 0 || (M.kind != K_DICT_STR && M.kind != K_DELTA_STR) || M.entries_plain) return false;
     if ((M.front_blocks != 0) != parallel) return false;
     f.ec = M.entry_count;
@@ -768,9 +770,9 @@ __device__ __forceinline__ bool front_ctx(FrontCtx& f, const DevPack& P, const P
     f.stride = M.front_stride;
     f.sfx = in + P.in_off + M.sfx_off;
     uint8_t* dict = str_dict_ptr(P, M, out, scratch);
-    f.doff = (const uint32_t*)dict;
+    f.doff = M.kind == K_DELTA_STR ? (const uint32_t*)dict : (const uint32_t*)(ro + P.s_dict);
     f.body = dict + 4ull * (f.ec + 1);
-    f.pre = (const int32_t*)(scratch + P.s_lens);
+    f.pre = (const int32_t*)(ro + P.s_lens);
     f.suf = f.pre + lens_stride(P.obj_count);
     f.sufoff = (const uint32_t*)(f.suf + lens_stride(P.obj_count));
     f.sum = (uint16_t*)(out + (use_ds ? P.ds_off : P.out_off));
@@ -783,7 +785,7 @@ __global__ __launch_bounds__(64) void k_front_serial(const DevPack* __restrict__
     const int pi = list[blockIdx.y];
     const DevPack P = packs[pi];
     FrontCtx f;
-    if (!front_ctx(f, P, metas[pi], in, out, scratch, 0, false)) return;
+    if (!front_ctx(f, P, metas[pi], in, out, scratch, scratch, 0, false)) return;
     const uint32_t max_len = metas[pi].max_len;
     const int lane = threadIdx.x;
     for (uint32_t col0 = blockIdx.x * 64; col0 < max_len; col0 += gridDim.x * 64) {
@@ -807,29 +809,47 @@ __global__ __launch_bounds__(64) void k_front_serial(const DevPack* __restrict__
 
 __global__ __launch_bounds__(256) void k_front_summary(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                        const PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
-                                                       uint8_t* __restrict__ out, uint8_t* __restrict__ scratch, int use_ds) {
-    const int pi = list[blockIdx.y];
-    const DevPack P = packs[pi];
+                                                       uint8_t* __restrict__ out, uint8_t* __restrict__ scratch,
+                                                       const uint8_t* __restrict__ ro, int use_ds) {
+    uint32_t bx, by;
+    pack_block_remap(bx, by);
+    const int pi = list[by];
+    const DevPack& P = packs[pi];
     FrontCtx f;
-    if (!front_ctx(f, P, metas[pi], in, out, scratch, use_ds, true)) return;
+    if (!front_ctx(f, P, metas[pi], in, out, scratch, ro, use_ds, true)) return;
     const int lane = threadIdx.x & 63;
-    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const uint32_t wave = bx * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     for (uint32_t b = wave; b < f.nblk; b += nwaves) {
         const uint32_t i0 = b * kFrontBlock;
         const uint32_t cnt = min((uint32_t)kFrontBlock, f.ec - i0);
         const uint32_t ii = min(i0 + lane, f.ec - 1);
         const uint32_t mp = (uint32_t)f.pre[ii], mlen = mp + (uint32_t)f.suf[ii], mso = f.sufoff[ii];
+        // The last writer of column j in this block is the last string k with prefixLen[k] <= j (for every column a later
+        // block can still inherit, i.e. j < length of the block's last string).  With M[k] = min(prefixLen[k..]) -- a
+        // non-decreasing sequence -- that k is (number of k with M[k] <= j) - 1: a binary search over the lanes.
+        uint32_t M = (uint32_t)lane < cnt ? mp : 0xFFFFFFFFu;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_down(M, d);
+            if (lane + d < 64) M = min(M, t);
+        }
+        const uint32_t len_last = __builtin_amdgcn_readlane(mlen, cnt - 1);
         for (uint32_t col0 = 0; col0 < f.stride; col0 += 64) {
             const uint32_t j = col0 + lane;
-            int w = -1;
-            for (uint32_t k = 0; k < cnt; k++) {
-                const uint32_t p = __builtin_amdgcn_readlane(mp, k), l = __builtin_amdgcn_readlane(mlen, k);
-                if (j >= p && j < l) w = (int)k;
+            uint32_t lo = 0;  // number of k with M[k] <= j, found bit by bit
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+                const uint32_t probe = lo + step - 1;  // is M[probe] <= j ?
+                const uint32_t mv = __shfl(M, (int)min(probe, 63u));
+                if (probe < cnt && mv <= j) lo += step;
             }
-            const int src = w < 0 ? 0 : w;
+            // lo in 0..63 from the loop; the 64th string needs one more probe
+            if (lo == 63 && cnt == 64 && (uint32_t)__shfl(M, 63) <= j) lo = 64;
+            const int owner = (int)lo - 1;
+            const int src = owner < 0 ? 0 : owner;
             const uint32_t wp = __shfl(mp, src), wso = __shfl(mso, src);
             uint32_t val = 0xFFFFu;
-            if (w >= 0) val = f.sfx[wso + (j - wp)];
+            if (owner >= 0 && j < len_last) val = f.sfx[wso + (j - wp)];
             f.sum[(size_t)b * f.stride + j] = (uint16_t)val;
         }
     }
@@ -841,7 +861,7 @@ __global__ __launch_bounds__(64) void k_front_combine(const DevPack* __restrict_
     const int pi = list[blockIdx.y];
     const DevPack P = packs[pi];
     FrontCtx f;
-    if (!front_ctx(f, P, metas[pi], in, out, scratch, use_ds, true)) return;
+    if (!front_ctx(f, P, metas[pi], in, out, scratch, scratch, use_ds, true)) return;
     const int lane = threadIdx.x;
     for (uint32_t col0 = blockIdx.x * 64; col0 < f.stride; col0 += gridDim.x * 64) {
         uint16_t* col = f.sum + col0 + lane;
@@ -867,33 +887,42 @@ __global__ __launch_bounds__(64) void k_front_combine(const DevPack* __restrict_
 
 __global__ __launch_bounds__(256) void k_front_decode(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                       const PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
-                                                      uint8_t* __restrict__ out, uint8_t* __restrict__ scratch, int use_ds) {
-    const int pi = list[blockIdx.y];
-    const DevPack P = packs[pi];
+                                                      uint8_t* __restrict__ out, uint8_t* __restrict__ scratch,
+                                                      const uint8_t* __restrict__ ro, int use_ds) {
+    uint32_t bx, by;
+    pack_block_remap(bx, by);
+    const int pi = list[by];
+    const DevPack& P = packs[pi];
     FrontCtx f;
-    if (!front_ctx(f, P, metas[pi], in, out, scratch, use_ds, true)) return;
+    if (!front_ctx(f, P, metas[pi], in, out, scratch, ro, use_ds, true)) return;
     const int lane = threadIdx.x & 63;
-    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(bx * 4 + (threadIdx.x >> 6)), nwaves = gridDim.x * 4;
     for (uint32_t b = wave; b < f.nblk; b += nwaves) {
         const uint32_t i0 = b * kFrontBlock;
         const uint32_t cnt = min((uint32_t)kFrontBlock, f.ec - i0);
+        // lane k holds the lengths and offsets of the block's string k; the loop below broadcasts them with readlane
         const uint32_t ii = min(i0 + lane, f.ec - 1);
-        const uint32_t mp = (uint32_t)f.pre[ii], ms = (uint32_t)f.suf[ii], mo = f.doff[ii], mso = f.sufoff[ii];
+        const uint32_t mp = (uint32_t)f.pre[ii], mso = f.sufoff[ii], mo = f.doff[ii];
+        const uint32_t mlen = (uint32_t)lane < cnt ? mp + (uint32_t)f.suf[ii] : 0u;  // length 0: no column takes part
+        const uint32_t msp = mso - mp;  // source position of column j is msp + j (for columns inside the suffix)
         for (uint32_t col0 = 0; col0 < f.stride; col0 += 64) {
             const uint32_t j = col0 + lane;
             uint32_t cur = f.sum[(size_t)b * f.stride + j];
+            // strings that end before our columns neither read nor write here: skip batches made of them only
+            const uint64_t reach = __ballot(mlen > col0);
             for (uint32_t k0 = 0; k0 < cnt; k0 += 8) {
+                if (((reach >> k0) & 0xFFu) == 0) continue;
                 // 8 strings per step: all suffix loads are issued before the first byte is consumed
                 uint32_t p[8], len[8], o[8], t[8];
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
-                    const uint32_t k = min(k0 + q, cnt - 1);
+                    const uint32_t k = k0 + q;  // <= 63; lanes >= cnt hold length 0
                     p[q] = __builtin_amdgcn_readlane(mp, k);
-                    len[q] = k0 + q < cnt ? p[q] + __builtin_amdgcn_readlane(ms, k) : 0u;  // len 0: no column takes part
+                    len[q] = __builtin_amdgcn_readlane(mlen, k);
                     o[q] = __builtin_amdgcn_readlane(mo, k);
-                    const uint32_t so = __builtin_amdgcn_readlane(mso, k);
+                    const uint32_t so = __builtin_amdgcn_readlane(mso, k), sp = __builtin_amdgcn_readlane(msp, k);
                     // unconditional, clamped load (so + 0 is always readable: suffix bytes are followed by the id stream)
-                    t[q] = f.sfx[so + ((j >= p[q] && j < len[q]) ? j - p[q] : 0u)];
+                    t[q] = f.sfx[(j >= p[q] && j < len[q]) ? sp + j : so];
                 }
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
@@ -1297,7 +1326,8 @@ void launch_front_serial(const LaunchCtx& c, const int* list, int count) {
 }
 void launch_front_summary(const LaunchCtx& c, const int* list, int count, int use_ds) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_front_summary, dim3(32, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch, use_ds);
+    hipLaunchKernelGGL(k_front_summary, dim3(32, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch,
+                       (const uint8_t*)c.scratch, use_ds);
 }
 void launch_front_combine(const LaunchCtx& c, const int* list, int count, int use_ds) {
     if (count <= 0) return;
@@ -1305,7 +1335,8 @@ void launch_front_combine(const LaunchCtx& c, const int* list, int count, int us
 }
 void launch_front_decode(const LaunchCtx& c, const int* list, int count, int use_ds) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_front_decode, dim3(64, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch, use_ds);
+    hipLaunchKernelGGL(k_front_decode, dim3(64, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch,
+                       (const uint8_t*)c.scratch, use_ds);
 }
 void launch_str_rows(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;
