@@ -376,8 +376,7 @@ extern "C" int32_t ixr_plan_run(ixr_plan* pl, const void* d_in, uint64_t in_byte
         T.run("k_dict_num<u32>", g.cnt[L_N32], [&] { launch_dict_num(c, L + g.off[L_N32], g.cnt[L_N32], 32); });
         T.run("k_dict_num<u64>", g.cnt[L_N64], [&] { launch_dict_num(c, L + g.off[L_N64], g.cnt[L_N64], 64); });
         T.run("k_copy_raw", g.cnt[L_RAW], [&] { launch_copy_raw(c, L + g.off[L_RAW], g.cnt[L_RAW]); });
-        T.run("k_str_rows", g.cnt[L_STR], [&] { launch_str_rows(c, L + g.off[L_STR], g.cnt[L_STR]); });
-        T.run("k_row_scan", g.cnt[L_STR], [&] { launch_row_scan(c, L + g.off[L_STR], g.cnt[L_STR]); });
+        T.run("k_str_index", g.cnt[L_STR], [&] { launch_str_index(c, L + g.off[L_STR], g.cnt[L_STR]); });
         T.run("k_str_copy", g.cnt[L_STR], [&] { launch_str_copy(c, L + g.off[L_STR], g.cnt[L_STR]); });
     }
     HIP_TRY(hipGetLastError(), return IXR_ERR_HIP);
@@ -436,7 +435,7 @@ static void attribute_bytes(ixr_plan* pl, const std::vector<PackMeta>& metas, st
                 const uint64_t index = 4 * (n + 1), body = ds > index ? ds - index : 0;
                 if (m.entries_plain) by["k_str_dict_scan"] += m.ids_off;
                 else { by["k_delta<u32>(str lens)"] += m.sfx_off; by[m.front_blocks ? "k_front_decode" : "k_front_serial"] += m.sfx_len; }
-                by["k_str_rows"] += (ps - m.ids_off) + index;
+                by["k_str_index"] += (ps - m.ids_off) + index;
                 by["k_str_copy"] += body;
                 break;
             }

@@ -18,7 +18,7 @@
 //                restart point.  Many independent chains per wave hide the load latency of each chain.
 //   k_delta      one workgroup per DELTA stream: bit-unpack + wave/workgroup prefix sum with a running carry.
 //   k_dict_num   one wave per 1024-row tile: expand ids from the restart point, gather dictionary entries, store rows.
-//   string packs k_str_dict_scan -> k_front_decode -> k_str_rows -> k_row_scan -> k_str_copy  (see each kernel)
+//   string packs k_str_dict_scan -> k_front_decode -> k_str_index -> k_str_copy  (see each kernel)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -466,15 +466,21 @@ __device__ __forceinline__ void rle_tile_expand(const uint8_t* base, uint32_t bw
     const uint32_t bytew = (bw + 7) >> 3;
     uint32_t pos = restart.x, o = restart.y;
     while (o < tile_end && pos < ids_end) {
-        // uniform header parse (every lane reads the same bytes)
-        uint32_t h = 0;
-        int shift = 0;
-        for (int i = 0; i < 5 && pos < ids_end; i++) {
-            uint32_t b = base[pos++];
-            h |= (b & 0x7F) << shift;
-            if (!(b & 0x80)) break;
-            shift += 7;
+        // uniform header parse: one 8-byte load covers the uvarint (<= 5 bytes) and a run's value (<= 2 bytes).  Reading
+        // past the stream's end stays inside the arena's slack; bytes at or beyond `ids_end` are not taken as header bytes.
+        uint64_t w;
+        __builtin_memcpy(&w, base + pos, 8);
+        const uint32_t avail = min(5u, ids_end - pos);
+        uint32_t h = 0, nb = 0;
+        bool open = true;
+#pragma unroll
+        for (uint32_t i = 0; i < 5; i++) {
+            const uint32_t b = (uint32_t)(w >> (8 * i)) & 0xFFu;
+            const bool take = open && i < avail;
+            if (take) { h |= (b & 0x7F) << (7 * i); nb = i + 1; }
+            open = take && (b & 0x80);
         }
+        pos += nb;
         const uint32_t cnt = h >> 1;
         const uint32_t lo = max(o, tile_start), hi = min(o + cnt, tile_end);
         if (h & 1) {
@@ -483,8 +489,7 @@ __device__ __forceinline__ void rle_tile_expand(const uint8_t* base, uint32_t bw
             for (uint32_t i = lo + lane; i < hi; i += 64) ids[i - tile_start] = (uint16_t)extract32(data, (i - o) * bw, bw);
             pos += ((cnt + 7) >> 3) * bw;
         } else {
-            uint32_t val = 0;
-            for (uint32_t b = 0; b < bytew; b++) val |= (uint32_t)base[pos + b] << (8 * b);
+            const uint32_t val = (uint32_t)(w >> (8 * nb)) & ((1u << (8 * bytew)) - 1u);  // bytew is 0..2
             for (uint32_t i = lo + lane; i < hi; i += 64) ids[i - tile_start] = (uint16_t)val;
             pos += bytew;
         }
@@ -537,21 +542,28 @@ __global__ __launch_bounds__(256) void k_dict_num(const DevPack* __restrict__ pa
     const uint2 restart = ((const uint2*)(scratch + P.s_restart))[t.tile];
     rle_tile_expand(base, M.id_bw, M.ids_off + 4 + M.ids_len, restart, t.tile_start, t.tile_end, ids);
     const uint32_t cnt = t.tile_end - t.tile_start, lane = threadIdx.x & 63;
+    // a lane takes two neighbouring rows of every 128: ids come out of LDS two at a time, results leave as 8 / 16 byte
+    // stores, and the 16 gathers are all in flight before the first store
     uint32_t id[16];
     bool bad = false;
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const uint32_t r = q * 64 + lane;
-        id[q] = r < cnt ? ids[r] : 0u;
-        if (id[q] >= t.ec) { bad = true; id[q] = 0; }
+    for (int q = 0; q < 8; q++) {
+        const uint32_t r = q * 128 + 2 * lane;
+        const uint32_t two = ((const uint32_t*)ids)[q * 64 + lane];
+        id[2 * q] = r < cnt ? (two & 0xFFFFu) : 0u;
+        id[2 * q + 1] = r + 1 < cnt ? (two >> 16) : 0u;
+        if (id[2 * q] >= t.ec) { bad = true; id[2 * q] = 0; }
+        if (id[2 * q + 1] >= t.ec) { bad = true; id[2 * q + 1] = 0; }
     }
     U v[16];
 #pragma unroll
     for (int q = 0; q < 16; q++) v[q] = dict[id[q]];
+    struct alignas(2 * sizeof(U)) Pair { U a, b; };
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const uint32_t r = q * 64 + lane;
-        if (r < cnt) dst[r] = v[q];
+    for (int q = 0; q < 8; q++) {
+        const uint32_t r = q * 128 + 2 * lane;
+        if (r + 1 < cnt) *(Pair*)(dst + r) = Pair{v[2 * q], v[2 * q + 1]};
+        else if (r < cnt) dst[r] = v[2 * q];
     }
     if (bad) metas[t.pi].status = E_CORRUPT;
 }
@@ -1013,6 +1025,102 @@ __global__ __launch_bounds__(256) void k_row_scan(const DevPack* __restrict__ pa
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// k_str_index: string dictionary packs, one workgroup of 16 waves per pack.  Per round each wave expands one tile of
+// kRleTile ids, looks up the rows' dictionary slices and scans the row lengths; the workgroup chains the 16 tiles and the
+// rounds with a running total.  Writes the output index (offset[0] = 0, offset[i+1] = offset[i] + len[i];
+// StringsStruct.Builder, StringsStruct.java:120-158) and each row's slice start into scratch, checks that the body fits,
+// zero-fills what the body leaves of dpn.dataSize.  (DictStruct.decodeStrings, DictStruct.java:97-110.)
+// Does in one pass what k_str_rows + k_row_scan do in two.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_str_index(const DevPack* __restrict__ packs, const int* __restrict__ list,
+                                                    PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
+                                                    uint8_t* __restrict__ out, uint8_t* __restrict__ scratch) {
+    constexpr int kWaves = 16;
+    __shared__ uint16_t s_ids[kWaves][kRleTile];
+    __shared__ uint32_t s_wsum[2][kWaves];
+    __shared__ unsigned long long s_tot;
+    const int pi = list[blockIdx.x];
+    PackMeta& M = metas[pi];
+    if (M.status < 0 || M.kind != K_DICT_STR) return;
+    const DevPack& P = packs[pi];
+    const uint32_t n = (uint32_t)P.obj_count, ec = M.entry_count;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (4ull * (n + 1) > (uint64_t)P.data_size) { if (tid == 0) M.status = E_OVERFLOW; return; }
+    const uint32_t body_cap = (uint32_t)P.data_size - 4u * (n + 1);
+    const uint8_t* base = in + P.in_off;
+    const uint32_t* __restrict__ doff = (const uint32_t*)(scratch + P.s_dict);
+    uint32_t* __restrict__ off = (uint32_t*)(out + P.out_off);
+    uint32_t* __restrict__ srcoff = (uint32_t*)(scratch + P.s_rows);
+    const uint2* restarts = (const uint2*)(scratch + P.s_restart);
+    const uint32_t id_bw = M.id_bw, ids_end = M.ids_off + 4 + M.ids_len;
+    uint16_t* ids = s_ids[wave];
+    __shared__ int s_bad;
+    if (tid == 0) { s_tot = 0; s_bad = 0; }
+    const uint32_t ntiles = (n + kRleTile - 1) / kRleTile;
+    uint32_t carry = 0;   // offset of the round's first row (mod 2^32; the exact total is kept in sum64)
+    uint64_t sum64 = 0;   // this lane's share of the exact total
+    bool bad = false;
+    for (uint32_t t0 = 0, round = 0; t0 < ntiles; t0 += kWaves, round++) {
+        const uint32_t tile = t0 + wave;
+        const uint32_t tile_start = min(tile * (uint32_t)kRleTile, n), tile_end = min(n, tile_start + (uint32_t)kRleTile);
+        const uint32_t cnt = tile_end - tile_start;  // 0 for waves past the last tile
+        if (cnt) rle_tile_expand(base, id_bw, ids_end, restarts[tile], tile_start, tile_end, ids);
+        uint2 ab[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const uint32_t r = q * 64 + lane;
+            uint32_t id = r < cnt ? ids[r] : 0u;
+            if (id >= ec) { bad = true; id = 0; }
+            __builtin_memcpy(&ab[q], doff + id, 8);  // doff[id], doff[id + 1]
+        }
+        // rows are dealt to lanes 64 at a time: scan each group of 64 across the wave, chain the groups
+        uint32_t ex[16], run = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const uint32_t r = q * 64 + lane;
+            const uint32_t len = r < cnt ? ab[q].y - ab[q].x : 0u;
+            sum64 += len;
+            const uint32_t inc = wave_incl_scan(len);
+            ex[q] = run + inc - len;
+            run += __builtin_amdgcn_readlane(inc, 63);
+        }
+        if (lane == 0) s_wsum[round & 1][wave] = run;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; w++) {
+            const uint32_t v = s_wsum[round & 1][w];
+            before += w < wave ? v : 0u;
+            total += v;
+        }
+        const uint32_t o0 = carry + before;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const uint32_t r = q * 64 + lane;
+            if (r < cnt) { off[tile_start + r] = o0 + ex[q]; srcoff[tile_start + r] = ab[q].x; }
+        }
+        carry += total;
+    }
+    // exact total: detects a body that does not fit even when the 32-bit offsets wrapped
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum64 += __shfl_xor(sum64, d);
+    if (lane == 0) atomicAdd(&s_tot, (unsigned long long)sum64);
+    if (bad) s_bad = 1;
+    __syncthreads();
+    const uint64_t tot64 = s_tot;
+    if (s_bad) { if (tid == 0) M.status = E_CORRUPT; return; }
+    if (tot64 > body_cap) {  // the body must fit dpn.dataSize = index + body (DataPackCreator_VLT.java:185-205)
+        if (tid == 0) M.status = E_OVERFLOW;
+        return;
+    }
+    if (tid == 0) off[n] = (uint32_t)tot64;
+    // A body shorter than dpn.dataSize promises leaves a tail: the reference decodes into a zero-filled direct buffer
+    // (PackCompressor_VLT.java:133, ByteBufferUtil.java:31-36), so the tail reads as zeros.
+    uint8_t* tail = out + P.out_off + 4ull * (n + 1) + tot64;
+    for (uint64_t i = tid; i < body_cap - tot64; i += 1024) tail[i] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // k_str_copy: string dictionary packs: body[offset[i] .. offset[i+1]) = dictBody[srcOff[i] ..].  One workgroup per tile of
 // kStrTileRows rows; the tile's offsets are staged in LDS.  Each lane produces 16-byte aligned chunks of the output body:
 // a branch-free binary search in the staged offsets finds the row of the chunk's first byte, then every row that
@@ -1342,6 +1450,10 @@ void launch_str_rows(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;
     hipLaunchKernelGGL(k_str_rows, dim3(IXR_PACK_TILES / 4, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out,
                        c.scratch);
+}
+void launch_str_index(const LaunchCtx& c, const int* list, int count) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_str_index, dim3(count), dim3(1024), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
 }
 void launch_row_scan(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;

@@ -31,6 +31,7 @@ void launch_front_combine(const LaunchCtx& c, const int* list, int count, int us
 void launch_front_decode(const LaunchCtx& c, const int* list, int count, int use_ds);
 void launch_str_rows(const LaunchCtx& c, const int* list, int count);
 void launch_row_scan(const LaunchCtx& c, const int* list, int count);
+void launch_str_index(const LaunchCtx& c, const int* list, int count);
 void launch_str_copy(const LaunchCtx& c, const int* list, int count);
 void launch_ds_meta(const LaunchCtx& c, const int* list, int count);
 void launch_ds_rows(const LaunchCtx& c, const int* list, int count, int mode);  // 0: 32 bit, 1: 64 bit, 2: strings
