@@ -198,8 +198,9 @@ def main():
         per_launch = dom["alg_bytes_per_step"] * args.steps / max(dom["launches"], 1)
         achieved = per_launch / (dom["avg_ms"] / 1e3) / 1e9 if dom["avg_ms"] > 0 else 0.0
         whole = (plan.total_in + plan.total_out) * args.steps / elapsed / 1e9
+        traffic, traffic_src = pmc_traffic(dom["name"], "%s, %d rows per GPU" % (desc_text, rows))
         roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "alg_bytes_per_launch": int(per_launch), "avg_launch_ms": dom["avg_ms"],
                     "whole_job": {"achieved": round(whole, 1), "frac": round(whole / HBM_PEAK_GBS, 4),
                                   "alg_bytes_per_step": plan.total_in + plan.total_out,
@@ -247,6 +248,24 @@ def main():
     d_out.free()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel, workload_prefix):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes (hardware counters cannot be read from
+    inside this process; tools/profile.sh + tools/pmc_traffic.py produce the file).  None unless the file was measured on
+    this very workload."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            doc = json.load(fh)
+    except (OSError, ValueError):
+        return None, None
+    if not str(doc.get("workload", "")).startswith(workload_prefix):
+        return None, None
+    k = doc.get("kernels", {}).get(kernel)
+    if not k or not k.get("hbm_bytes_per_launch"):
+        return None, None
+    return int(k["hbm_bytes_per_launch"]), "profiles/pmc_traffic.json (%s)" % doc.get("source", "")
 
 
 def time_cpu_oracle(np, sample, threads, target_s, log):
