@@ -65,6 +65,8 @@ def main():
     import numpy as np
 
     from indexr_amd import lib as L
+    from indexr_amd import shard as S
+    from indexr_amd import table as T
 
     device = local_rank if world > 1 else 0
     rc = L.lib.ixr_init(device)
@@ -78,9 +80,8 @@ def main():
         kinds = [int(k) for k in args.kinds.split(",")]
         desc_text = "experiment: synthetic column kinds %s" % kinds
     rows = args.rows
-    n_packs = (rows + 65535) >> 16  # DataPack.rowCountToPackCount (DataPack.java:773-803)
-    last_rows = rows - (n_packs - 1) * 65536
-    first_pack = rank * n_packs  # this rank's contiguous range of pack ids (SegmentAssigner-style contiguous split)
+    n_packs = T.pack_count(rows)  # DataPack.rowCountToPackCount (DataPack.java:773-803)
+    first_pack = S.weak_scaling_first_pack(rank, n_packs)  # this rank's contiguous range of pack ids
 
     def log(msg):
         if rank == 0:
@@ -88,35 +89,12 @@ def main():
 
     # ------------------------------------------------------------------ build the compressed table, chunk by chunk
     t0 = time.time()
-    chunk_packs = 1024
-    host_chunks, all_descs, all_sums = [], [], []
-    in_off = out_off = 0
-    sample_for_cpu = None
-    for c0 in range(0, n_packs, chunk_packs):
-        c1 = min(n_packs, c0 + chunk_packs)
-        reqs = []
-        for p in range(c0, c1):
-            r = last_rows if p == n_packs - 1 else 65536
-            for k in kinds:
-                reqs.append((k, first_pack + p, r, 0))
-        descs, arena, chunk_out, sums = L.synth_build(reqs, args.seed, threads=threads)
-        body = len(arena) - L.IN_SLACK
-        for d in descs:
-            all_descs.append(L.PackDesc(d.in_off + in_off, d.out_off + out_off, d.pack_size, d.data_size, d.obj_count,
-                                        d.encode_type, d.data_type, 0))
-        all_sums.append(sums)
-        if sample_for_cpu is None:
-            sample_for_cpu = (list(descs), arena)
-        host_chunks.append((in_off, arena[:body]))
-        in_off += body
-        out_off += chunk_out
-        if (c0 // chunk_packs) % 4 == 0:
-            log("built %d / %d packs per column (%.0f s)" % (c1, n_packs, time.time() - t0))
-    in_bytes = in_off + L.IN_SLACK
-    out_bytes = out_off + 16
-    sums = np.concatenate(all_sums)
+    table = T.build_table(kinds, rows, first_pack, args.seed, threads=threads, log=log)
+    all_descs, host_chunks, sums, sample_for_cpu = table.descs, table.chunks, table.sums, table.sample
+    in_bytes, out_bytes = table.in_bytes, table.out_bytes
+    in_off = in_bytes - L.IN_SLACK
     log("input built in %.1f s with %d threads: %d packs, %.2f GB compressed -> %.2f GB decoded"
-        % (time.time() - t0, threads, len(all_descs), in_off / 1e9, out_off / 1e9))
+        % (time.time() - t0, threads, len(all_descs), in_off / 1e9, (out_bytes - 16) / 1e9))
 
     # ------------------------------------------------------------------ move to HBM, plan
     d_in = L.DeviceBuffer(device, in_bytes)
@@ -159,13 +137,9 @@ def main():
     ktimes = plan.kernel_times()
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        # the optional gather of decoded row counts: 3 counters per rank over RCCL, nothing on the data path
-        cnt = torch.tensor([plan.total_rows, plan.total_out, plan.total_in, bad], dtype=torch.int64, device="cuda")
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        tot_rows, tot_out, tot_in, bad_all = [int(v) for v in cnt.tolist()]
+        # max-over-ranks time and the optional gather of decoded row counts: 4 counters per rank over RCCL
+        elapsed, (tot_rows, tot_out, tot_in, bad_all) = T.reduce_over_ranks(
+            dist, torch, "cuda", elapsed, [plan.total_rows, plan.total_out, plan.total_in, bad])
     else:
         tot_rows, tot_out, tot_in, bad_all = plan.total_rows, plan.total_out, plan.total_in, bad
     if bad_all:
