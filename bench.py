@@ -46,17 +46,27 @@ def parse_args():
     ap.add_argument("--scratch-gib", type=float, default=8.0)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU time of each cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the N > 1 code path on one GPU")
     ap.add_argument("--with-copies", action="store_true", help="also time H2D + decode + D2H from/to pinned host memory on a sample")
     return ap.parse_args()
 
 
 def main():
     args = parse_args()
+    # Native libraries (RCCL's version banner, HIP warnings) write to file descriptor 1; the contract is ONE JSON line on
+    # stdout.  Keep the real stdout aside and route everything else to stderr.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29513")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         # torch first: libixrgpu then binds to the HIP runtime torch bundles (same soname), one runtime per process.
         import torch
         import torch.distributed as dist
@@ -216,7 +226,8 @@ def main():
         }
         if with_copies:
             out["with_copies"] = with_copies
-        print(json.dumps(out), flush=True)
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
     plan.destroy()
     d_in.free()
     d_out.free()
