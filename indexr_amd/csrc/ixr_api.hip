@@ -104,6 +104,7 @@ extern "C" int32_t ixr_dev_synchronize(int32_t device) {
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 
+static_assert(kInSlack == IXR_IN_SLACK, "device code and the C ABI must agree on the arena slack");
 constexpr uint64_t kDefaultScratchBudget = 8ull << 30;
 constexpr int kMaxGroupPacks = 32768;  // grid.y limit is 65535
 
@@ -171,7 +172,7 @@ static ScratchNeed pack_scratch_layout(DevPack& p, uint64_t dict_cap_override) {
         if (dict) {
             p.dict_cap = dict_cap_override ? dict_cap_override : cap * (uint64_t)(p.width / 8);
             p.s_dict = take_b(p.dict_cap + 16);
-            p.s_restart = take_i(8 * ((cap + kRleTile - 1) / kRleTile));
+            p.s_restart = take_i(16 * ((cap + kRleTile - 1) / kRleTile));
         }
     } else {
         p.s_idx[1] = take_i(idx);
@@ -180,7 +181,7 @@ static ScratchNeed pack_scratch_layout(DevPack& p, uint64_t dict_cap_override) {
             p.dict_cap = dict_cap_override ? dict_cap_override : (uint64_t)p.data_size;
             p.s_dict = take_b(p.dict_cap + 32);
             p.s_rows = take_b(4 * cap + 16);
-            p.s_restart = take_i(8 * ((cap + kRleTile - 1) / kRleTile));
+            p.s_restart = take_i(16 * ((cap + kRleTile - 1) / kRleTile));
         }
     }
     return {oi, ob};

@@ -18,6 +18,7 @@ constexpr int kFrontBlock = 64;    // strings per block of the parallel front-co
 // Element stride of the per-pack string length arrays (prefixLen / suffixLen / sufOff): obj_count rounded up to 4 so that
 // each array starts 16-byte aligned.
 // >= obj_count + 9: one terminating entry plus the 7 entries an 8-wide metadata read may touch past the last string
+constexpr uint32_t kInSlack = 16;  // readable bytes after every pack in the input arena (IXR_IN_SLACK of the C ABI)
 __host__ __device__ inline uint32_t lens_stride(int32_t obj_count) { return ((uint32_t)obj_count + 12u) & ~3u; }
 
 // What the parse kernel found a pack to be.
@@ -44,7 +45,7 @@ struct DevPack {
     uint64_t s_idx[2];   // DELTA index of stream 0 / 1:  int64 minDelta[ceil(cap/128)] | uint32 mb[ceil(cap/32)]
     uint64_t s_dict;     // decoded dictionary, aligned: numbers entryCount*w ; strings a StringsStruct
     uint64_t dict_cap;   // bytes available at s_dict
-    uint64_t s_restart;  // RLE restart points: uint2[ceil(cap/kRleTile)] = (header offset in pack, first row of segment)
+    uint64_t s_restart;  // RLE restart records: uint4[ceil(cap/kRleTile)] = (payload offset, first row, row count, packed | run value << 1)
     uint64_t s_lens;     // strings: int32 prefixLen[S] | int32 suffixLen[S] | uint32 sufOff[S], S = lens_stride(obj_count) >= cap+9
     uint64_t s_rows;     // strings: uint32 srcOff[cap] (offset of each row's bytes inside the dictionary body)
     uint64_t ds_off;     // only for the getDictStruct run: where to write the DictStruct in the output arena

@@ -13,9 +13,9 @@
 // (paths relative to indexr-vlt-segment/src/main/java/io/indexr/vlt/codec/ and indexr-common/.../data/ of the reference)
 //
 // Pipeline per group of packs (one launch each, thousands of packs per launch):
-//   k_parse      one lane per serial stream: walks the data-dependent framing (mini-block widths, RLE headers), validates
-//                it and leaves an index: per mini-block (offset,width), per block minDelta, per 1024-row tile an RLE
-//                restart point.  Many independent chains per wave hide the load latency of each chain.
+//   k_parse      one wave per serial stream: walks the data-dependent framing (mini-block widths, RLE headers) through an
+//                LDS window, validates it and leaves an index: per mini-block (offset,width), per block minDelta, per
+//                1024-row tile the RLE segment covering its first row.
 //   k_delta      one workgroup per DELTA stream: bit-unpack + wave/workgroup prefix sum with a running carry.
 //   k_dict_num   one wave per 1024-row tile: expand ids from the restart point, gather dictionary entries, store rows.
 //   string packs k_str_dict_scan -> k_front_decode -> k_str_index -> k_str_copy  (see each kernel)
@@ -71,31 +71,104 @@ template <> __device__ __forceinline__ uint64_t extract<uint64_t>(const uint8_t*
 __device__ __forceinline__ uint32_t bit_width32(uint32_t v) { return v ? 32u - (uint32_t)__clz((int)v) : 0u; }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_parse: serial framing walk, one lane per stream (4 lanes per pack: DELTA stream 0, DELTA stream 1, RLE ids, spare)
+// Stream window: a wave keeps kWin bytes of a pack in LDS and reads the data-dependent framing (varints, width bytes, RLE
+// headers) from there.  One coalesced global load fills the window; every step of a serial walk then costs an LDS round
+// trip instead of a trip to L2/HBM.  All lanes of the wave call these functions with the same arguments.
 // ---------------------------------------------------------------------------------------------------------------
-struct Walker {
-    const uint8_t* base;  // pack start
-    uint32_t pos;         // current offset in the pack
-    uint32_t end;         // one past the last readable offset of the current stream
-    int32_t err;
-    __device__ __forceinline__ uint32_t u8() {
-        if (pos >= end) { err = E_CORRUPT; return 0; }
-        return base[pos++];
+constexpr uint32_t kWin = 4096;
+constexpr uint32_t kWinAlloc = kWin + 16;  // bytes of LDS per window (16 spare bytes so that 12-byte peeks never run off)
+
+struct Win {
+    const uint8_t* base;  // pack start in global memory, 16-byte aligned
+    uint32_t limit16;     // bytes readable from `base` in whole 16-byte chunks (pack + arena slack, rounded down)
+    uint8_t* lds;         // kWinAlloc bytes, 16-byte aligned
+    uint32_t w0;          // pack offset held by lds[0]; the window is [w0, w0 + kWin)
+
+    __device__ __forceinline__ void init(const uint8_t* b, uint32_t pack_size, uint8_t* l) {
+        base = b; limit16 = __builtin_amdgcn_readfirstlane((pack_size + kInSlack) & ~15u); lds = l; w0 = 0xFFFFFFFFu;
     }
-    // VarInteger.readUnsignedVarInt / readUnsignedVarLong (VarInteger.java:68-96); at most 5 / 10 bytes
-    __device__ __forceinline__ uint64_t uvarint(int max_bytes) {
-        uint64_t v = 0;
-        int shift = 0;
-        for (int i = 0; i < max_bytes; i++) {
-            uint32_t b = u8();
-            v |= (uint64_t)(b & 0x7F) << shift;
-            if (!(b & 0x80)) return v;
-            shift += 7;
+    // LDS instructions of one wave execute in program order, so a wavefront-scope fence (no wait on outstanding global
+    // stores or loads) plus a scheduling barrier is all that ordering window writes against window reads needs.
+    static __device__ __forceinline__ void wave_lds_sync() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ void load(uint32_t pos) {
+        const int lane = threadIdx.x & 63;
+        wave_lds_sync();
+        w0 = __builtin_amdgcn_readfirstlane(pos & ~15u);
+        // all chunk loads are issued before the first is consumed: out-of-range chunks re-read the last valid one
+        uint4 v[kWin / 1024];
+#pragma unroll
+        for (uint32_t i = 0; i < kWin / 1024; i++) {
+            const uint32_t off = w0 + i * 1024 + lane * 16;  // multiple of 16, so an in-range chunk ends <= limit16
+            v[i] = *(const uint4*)(base + min(off, limit16 - 16u));
+            if (off >= limit16) v[i] = make_uint4(0, 0, 0, 0);
         }
-        err = E_CORRUPT;
-        return v;
+#pragma unroll
+        for (uint32_t i = 0; i < kWin / 1024; i++) *(uint4*)(lds + i * 1024 + lane * 16) = v[i];
+        if (lane == 0) *(uint4*)(lds + kWin) = make_uint4(0, 0, 0, 0);
+        wave_lds_sync();
+    }
+    // make [pos, pos + bytes) part of the window (bytes <= kWin - 16)
+    __device__ __forceinline__ void need(uint32_t pos, uint32_t bytes) {
+        if (pos < w0 || pos + bytes > w0 + kWin) load(pos);
+    }
+    // The walkers below read the same address in every lane; readfirstlane tells the compiler so, which keeps the whole
+    // chain (positions, widths, branches) in scalar registers and scalar branches.
+    __device__ __forceinline__ uint32_t u8(uint32_t pos) const {  // pos must be in the window
+        return __builtin_amdgcn_readfirstlane((uint32_t)lds[pos - w0]);
+    }
+    // little-endian 64 bits at pack offset `pos`; [pos, pos + 8) must be in the window
+    __device__ __forceinline__ uint64_t peek64(uint32_t pos) const {
+        const uint32_t idx = pos - w0, a = idx & ~3u, sh = (idx & 3u) * 8u;
+        const uint32_t* q = (const uint32_t*)(lds + a);
+        const uint64_t lo = (uint64_t)q[0] | ((uint64_t)q[1] << 32);
+        return sh ? ((lo >> sh) | ((uint64_t)q[2] << (64 - sh))) : lo;
+    }
+    // the same for a position that is equal in all lanes: the three dwords go to scalar registers first, the shifts
+    // that assemble the result are scalar
+    __device__ __forceinline__ uint64_t peek64u(uint32_t pos) const {
+        const uint32_t idx = pos - w0, a = idx & ~3u, sh = (idx & 3u) * 8u;
+        const uint32_t* q = (const uint32_t*)(lds + a);
+        const uint32_t q0 = __builtin_amdgcn_readfirstlane(q[0]), q1 = __builtin_amdgcn_readfirstlane(q[1]);
+        const uint32_t q2 = __builtin_amdgcn_readfirstlane(q[2]);
+        const uint64_t lo = (uint64_t)q0 | ((uint64_t)q1 << 32);
+        return sh ? ((lo >> sh) | ((uint64_t)q2 << (64 - sh))) : lo;
+    }
+    // bits [bit, bit + bw) of the bit string starting at pack offset `pos`, bw <= 25; the bytes must be in the window
+    __device__ __forceinline__ uint32_t bits(uint32_t pos, uint32_t bit, uint32_t bw) const {
+        const uint32_t idx = pos - w0 + (bit >> 3), a = idx & ~3u, sh = (idx & 3u) * 8u + (bit & 7u);
+        const uint32_t* q = (const uint32_t*)(lds + a);
+        const uint64_t w = (uint64_t)q[0] | ((uint64_t)q[1] << 32);
+        return (uint32_t)(w >> sh) & ((1u << bw) - 1u);
     }
 };
+
+// VarInteger.readUnsignedVarInt / readUnsignedVarLong (VarInteger.java:68-96) out of the window: at most `max_bytes`
+// (5 or 10) bytes, none at or beyond `end`.  Returns the value, advances pos; sets err when the varint runs off the stream
+// or does not terminate.
+__device__ __forceinline__ uint64_t win_uvarint(Win& w, uint32_t& pos, uint32_t end, int max_bytes, int32_t& err) {
+    if (pos >= end) { err = E_CORRUPT; return 0; }
+    w.need(pos, 16);
+    const uint64_t lo = w.peek64u(pos);
+    if (!(lo & 0x80u)) { pos++; return lo & 0x7Fu; }  // one-byte varint: the common case
+    const uint64_t hi = w.peek64u(pos + 8);  // bytes 8 and 9 of a long varint
+    const uint32_t avail = min((uint32_t)max_bytes, end - pos);
+    uint64_t v = 0;
+    uint32_t used = 0;
+    bool open = true, terminated = false;
+#pragma unroll
+    for (uint32_t i = 0; i < 10; i++) {
+        const uint32_t b = (uint32_t)((i < 8 ? lo : hi) >> (8 * (i & 7))) & 0xFFu;
+        const bool take = open && i < avail;
+        if (take) { v |= (uint64_t)(b & 0x7F) << (7 * i); used = i + 1; terminated = !(b & 0x80u); }
+        open = take && (b & 0x80u);
+    }
+    pos += used;
+    if (!terminated) err = E_CORRUPT;  // ran into the end of the stream, or max_bytes continuation bytes
+    return v;
+}
 
 // VarInteger.readZigZagVarInt / readZigZagVarLong (VarInteger.java:106-127)
 __device__ __forceinline__ int64_t unzigzag32(uint64_t raw) {
@@ -104,80 +177,134 @@ __device__ __forceinline__ int64_t unzigzag32(uint64_t raw) {
 }
 __device__ __forceinline__ int64_t unzigzag64(uint64_t r) { return (int64_t)((r >> 1) ^ (0ull - (r & 1ull))); }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_parse: serial framing walk.  One workgroup per pack, one wave per serial stream (wave 0 and 1: the DELTA streams,
+// wave 2: the RLE id stream); each wave follows its chain through an LDS window.
+// ---------------------------------------------------------------------------------------------------------------
 // Walk one DELTA stream (DeltaCodec.decodeInts/decodeLongs framing, DeltaCodec.java:100-141, 204-245) and write its index.
-__device__ int32_t walk_delta(const uint8_t* base, uint32_t pack_size, uint32_t off, uint32_t n, int width,
-                              int64_t* min_delta, uint32_t* mb, int64_t* first_out, bool write) {
-    Walker w{base, off, pack_size, 0};
+__device__ int32_t walk_delta(Win& w, uint32_t pack_size, uint32_t off, uint32_t n, int width, int64_t* min_delta, uint32_t* mb,
+                              int64_t* first_out) {
+    const int lane = threadIdx.x & 63;
+    // the arguments are equal in all lanes; say so, so that the chain below stays in scalar registers
+    pack_size = __builtin_amdgcn_readfirstlane(pack_size);
+    off = __builtin_amdgcn_readfirstlane(off);
+    n = __builtin_amdgcn_readfirstlane(n);
+    width = __builtin_amdgcn_readfirstlane(width);
     if (off + 4 > pack_size) return E_CORRUPT;
-    int32_t len = (int32_t)ld32u(base + off);
+    const int32_t len = (int32_t)__builtin_amdgcn_readfirstlane(ld32u(w.base + off));
     if (len < 0 || (uint64_t)off + 4 + (uint64_t)len > pack_size) return E_CORRUPT;
-    w.pos = off + 4;
-    w.end = off + 4 + (uint32_t)len;
+    uint32_t pos = off + 4;
+    const uint32_t end = off + 4 + (uint32_t)len;
+    int32_t err = 0;
     const int vb = width == 32 ? 5 : 10;
-    uint64_t raw = w.uvarint(vb);
+    uint64_t raw = win_uvarint(w, pos, end, vb, err);
     *first_out = width == 32 ? unzigzag32(raw) : unzigzag64(raw);
-    uint32_t nb = (n + kBlock - 1) / kBlock;
-    for (uint32_t b = 0; b < nb && !w.err; b++) {
-        raw = w.uvarint(vb);
-        int64_t md = width == 32 ? unzigzag32(raw) : unzigzag64(raw);
-        if (write) min_delta[b] = md;
-        uint32_t cnt = min((uint32_t)kBlock, n - b * kBlock);
-        for (uint32_t m = 0; m * kMini < cnt; m++) {
-            uint32_t c = min((uint32_t)kMini, cnt - m * kMini);
-            uint32_t bw = w.u8();
-            if (bw > (uint32_t)width) w.err = E_CORRUPT;
-            if (w.err) break;
-            if (w.pos >= (1u << 24)) { w.err = E_CORRUPT; break; }
-            if (write) mb[b * 4 + m] = w.pos | (bw << 24);
-            w.pos += ((c + 7) >> 3) * bw;
-            if (w.pos > w.end) { w.err = E_CORRUPT; break; }
+    const uint32_t nb = (n + kBlock - 1) / kBlock;
+    // a block is at most 10 + 4 * (1 + 4 * width) bytes: one window check per block, then plain LDS byte reads
+    const uint32_t block_max = 10u + 4u * (1u + 4u * (uint32_t)width) + 16u;
+    for (uint32_t b = 0; b < nb && !err; b++) {
+        if (pos >= end) { err = E_CORRUPT; break; }
+        w.need(pos, block_max);
+        const uint32_t b0 = w.u8(pos);
+        if (b0 < 0x80u) { raw = b0; pos++; }                      // one-byte varint: the common case
+        else raw = win_uvarint(w, pos, end, vb, err);
+        if (err) break;
+        const int64_t md = width == 32 ? unzigzag32(raw) : unzigzag64(raw);
+        const uint32_t cnt = min((uint32_t)kBlock, n - b * kBlock);
+        uint32_t word[4] = {0, 0, 0, 0};
+        if (cnt == (uint32_t)kBlock) {
+            // full block: four mini-blocks of 32 values, 4 * bw payload bytes each.  Positions only grow, so running off the
+            // stream (or past the 24 bits an index word holds) shows in the final position: one check per block.  Bytes
+            // read beyond the stream's end in the meantime come from the window (zero filled past the arena's slack).
+            bool bad_bw = false;
+#pragma unroll
+            for (uint32_t m = 0; m < 4; m++) {
+                const uint32_t bw = w.u8(pos);
+                bad_bw |= bw > (uint32_t)width;
+                word[m] = (pos + 1) | (bw << 24);
+                pos += 1 + 4 * min(bw, (uint32_t)width);
+            }
+            if (bad_bw || pos > end || pos >= (1u << 24)) err = E_CORRUPT;
+        } else {
+#pragma unroll
+            for (uint32_t m = 0; m < 4; m++) {
+                if (m * kMini < cnt && !err) {
+                    const uint32_t c = min((uint32_t)kMini, cnt - m * kMini);
+                    if (pos >= end) { err = E_CORRUPT; break; }
+                    const uint32_t bw = w.u8(pos);
+                    pos++;
+                    if (bw > (uint32_t)width || pos >= (1u << 24)) { err = E_CORRUPT; break; }
+                    word[m] = pos | (bw << 24);
+                    pos += ((c + 7) >> 3) * bw;
+                    if (pos > end) { err = E_CORRUPT; break; }
+                }
+            }
         }
+        if (err) break;
+        if (lane == 0) min_delta[b] = md;
+        if (lane < 4 && (uint32_t)lane * kMini < cnt) mb[b * 4 + lane] = lane == 0 ? word[0] : lane == 1 ? word[1] : lane == 2 ? word[2] : word[3];
     }
-    if (!w.err && w.pos != w.end) w.err = E_CORRUPT;
-    return w.err;
+    if (!err && pos != end) err = E_CORRUPT;
+    return err;
 }
 
 // Walk the RLE/bit-packing hybrid id stream (RLEPackingHybridCodec.decodeInts, RLEPackingHybridCodec.java:97-128) and
-// record, for every tile of kRleTile rows, the segment header that covers the tile's first row.
-__device__ int32_t walk_rle(const uint8_t* base, uint32_t off, uint32_t len, uint32_t n, uint32_t bw, uint2* restart, bool write) {
-    Walker w{base, off + 4, off + 4 + len, 0};
+// record, for every tile of kRleTile rows, the segment that covers the tile's first row:
+//   x = pack offset of the segment's payload (bit-packed values), or of the byte after a run's value
+//   y = first row of the segment, z = its row count, w = 1 for bit-packed segments, (run value << 1) for runs
+__device__ int32_t walk_rle(Win& w, uint32_t off, uint32_t len, uint32_t n, uint32_t bw, uint4* restart) {
+    const int lane = threadIdx.x & 63;
+    off = __builtin_amdgcn_readfirstlane(off);
+    len = __builtin_amdgcn_readfirstlane(len);
+    n = __builtin_amdgcn_readfirstlane(n);
+    bw = __builtin_amdgcn_readfirstlane(bw);
+    uint32_t pos = off + 4;
+    const uint32_t end = off + 4 + len;
     const uint32_t bytew = (bw + 7) >> 3;
     uint32_t o = 0, next_tile = 0;
-    while (w.pos < w.end) {
-        uint32_t hp = w.pos;
-        uint32_t h = (uint32_t)w.uvarint(5);
-        if (w.err) break;
-        uint32_t cnt = h >> 1;
-        uint64_t payload = (h & 1) ? (uint64_t)((cnt + 7) >> 3) * bw : bytew;
-        if ((uint64_t)w.pos + payload > w.end || cnt > n - o) { w.err = E_CORRUPT; break; }
+    int32_t err = 0;
+    while (pos < end) {
+        const uint32_t h = (uint32_t)win_uvarint(w, pos, end, 5, err);
+        if (err) break;
+        const uint32_t cnt = h >> 1;
+        const bool packed = h & 1;
+        const uint64_t payload = packed ? (uint64_t)((cnt + 7) >> 3) * bw : bytew;
+        if ((uint64_t)pos + payload > end || cnt > n - o) { err = E_CORRUPT; break; }
         if (cnt) {
-            while (next_tile * (uint32_t)kRleTile < o + cnt) {
-                if (write) restart[next_tile] = make_uint2(hp, o);
-                next_tile++;
+            const uint32_t t1 = (o + cnt + kRleTile - 1) / kRleTile;  // tiles [next_tile, t1) start inside this segment
+            if (next_tile < t1) {
+                uint32_t val = 0;
+                if (!packed) {  // the value bytes follow the header; a header is <= 5 bytes, so a fresh 8-byte peek covers them
+                    val = (uint32_t)w.peek64u(pos) & ((1u << (8 * bytew)) - 1u);
+                }
+                const uint4 rec = make_uint4(packed ? pos : pos + bytew, o, cnt, packed ? 1u : (val << 1));
+                for (uint32_t t = next_tile + lane; t < t1; t += 64) restart[t] = rec;
+                next_tile = t1;
             }
         }
         o += cnt;
-        w.pos += (uint32_t)payload;
+        pos += (uint32_t)payload;
     }
-    if (!w.err && o != n) w.err = E_CORRUPT;  // Preconditions.checkState(valIndex == valCount) :126
-    return w.err;
+    if (!err && o != n) err = E_CORRUPT;  // Preconditions.checkState(valIndex == valCount) :126
+    return err;
 }
 
 __global__ __launch_bounds__(256) void k_parse(const DevPack* __restrict__ packs, const int* __restrict__ list, int count,
                                                PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                uint8_t* __restrict__ scratch) {
-    int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    int li = tid >> 2;
-    const int k = tid & 3;
-    const bool active = li < count;
-    if (!active) li = count - 1;  // keep the lane alive for the shuffles below; its writes are suppressed
-    const int pi = list[li];
+    __shared__ __align__(16) uint8_t s_win[3][kWinAlloc];
+    __shared__ int32_t s_werr[4];
+    __shared__ int64_t s_first[2];
+    const int k = threadIdx.x >> 6;  // wave = stream
+    const int pi = list[blockIdx.x];
     const DevPack P = packs[pi];
     const uint8_t* base = in + P.in_off;
     const uint32_t psz = (uint32_t)P.pack_size;
     const uint32_t n = (uint32_t)P.obj_count;
     const int W = P.width;  // 32, 64 or 0 (strings)
+    (void)count;
 
+    // every wave derives the pack's header fields (a few uniform loads); wave 0 publishes them
     PackMeta m;
     m.status = 0; m.kind = K_NONE; m.entry_count = 0; m.id_bw = 0; m.ids_off = 0; m.ids_len = 0; m.entries_off = 0;
     m.entries_plain = 0; m.sfx_off = 0; m.sfx_len = 0; m.dict_struct_size = 0; m.max_len = 0; m.front_blocks = 0; m.front_stride = 0;
@@ -299,28 +426,30 @@ __global__ __launch_bounds__(256) void k_parse(const DevPack* __restrict__ packs
     }
     if (!err && (consumed < 0 || consumed > (int64_t)psz)) err = E_CORRUPT;
 
-    // ---- the serial walks, one per lane
+    // ---- the serial walks, one per wave
     int32_t werr = 0;
     int64_t first = 0;
-    if (!err) {
+    if (!err && k < 3) {
+        Win w;
+        w.init(base, psz, s_win[k]);
         const StreamDesc sd = k == 0 ? m.s[0] : m.s[1];
         if (k < 2 && sd.n) {
             int64_t* md = (int64_t*)(scratch + (k == 0 ? P.s_idx[0] : P.s_idx[1]));
             uint32_t* mb = (uint32_t*)(md + (P.obj_count + kBlock - 1) / kBlock);
-            werr = walk_delta(base, psz, sd.in_off, sd.n, W ? W : 32, md, mb, &first, active);
+            werr = walk_delta(w, psz, sd.in_off, sd.n, W ? W : 32, md, mb, &first);
         } else if (k == 2 && has_ids) {
-            werr = walk_rle(base, m.ids_off, m.ids_len, n, m.id_bw, (uint2*)(scratch + P.s_restart), active);
+            werr = walk_rle(w, m.ids_off, m.ids_len, n, m.id_bw, (uint4*)(scratch + P.s_restart));
         }
     }
-    // ---- lane 0 of each group of 4 collects the results and writes the meta record
-    const int lane = threadIdx.x & 63;
-    const int g0 = lane & ~3;
-    int32_t e0 = __shfl(werr, g0), e1 = __shfl(werr, g0 + 1), e2 = __shfl(werr, g0 + 2);
-    int64_t f1 = __shfl(first, g0 + 1);
-    if (active && k == 0) {
-        m.s[0].first = first;
-        m.s[1].first = f1;
-        if (!err) err = e0 ? e0 : (e1 ? e1 : e2);
+    if ((threadIdx.x & 63) == 0) {
+        s_werr[k] = werr;
+        if (k < 2) s_first[k] = first;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m.s[0].first = s_first[0];
+        m.s[1].first = s_first[1];
+        if (!err) err = s_werr[0] ? s_werr[0] : (s_werr[1] ? s_werr[1] : s_werr[2]);
         m.status = err ? err : (int32_t)consumed;
         metas[pi] = m;
     }
@@ -456,49 +585,67 @@ __device__ __forceinline__ void pack_block_remap(uint32_t& bx, uint32_t& by) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// RLE tile expansion shared by the id-consuming kernels: a wave walks the segments that overlap its tile of kRleTile rows,
-// starting from the restart point the parse kernel left, and writes the tile's ids (always < 65536) into LDS.  The
-// consumers then read them back 16 rows per lane, which lets them keep 16 independent gathers in flight.
+// RLE tile expansion shared by the id-consuming kernels: a wave expands the ids (always < 65536) of its tile of kRleTile
+// rows into LDS.  It starts from the segment record the parse kernel left for the tile, pulls the tile's stretch of the id
+// stream into its LDS window with one coalesced load and walks the remaining segment headers there.  The consumers read
+// the ids back in the order that suits their stores, which also lets them keep 16 independent gathers in flight.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void rle_tile_expand(const uint8_t* base, uint32_t bw, uint32_t ids_end, uint2 restart,
-                                                uint32_t tile_start, uint32_t tile_end, uint16_t* ids) {
+__device__ __forceinline__ void rle_tile_expand(Win& w, uint32_t bw, uint32_t ids_end, uint4 seg, uint32_t tile_start,
+                                                uint32_t tile_end, uint16_t* ids) {
     const int lane = threadIdx.x & 63;
+    bw = __builtin_amdgcn_readfirstlane(bw);
+    ids_end = __builtin_amdgcn_readfirstlane(ids_end);
+    tile_start = __builtin_amdgcn_readfirstlane(tile_start);
+    tile_end = __builtin_amdgcn_readfirstlane(tile_end);
     const uint32_t bytew = (bw + 7) >> 3;
-    uint32_t pos = restart.x, o = restart.y;
-    while (o < tile_end && pos < ids_end) {
-        // uniform header parse: one 8-byte load covers the uvarint (<= 5 bytes) and a run's value (<= 2 bytes).  Reading
-        // past the stream's end stays inside the arena's slack; bytes at or beyond `ids_end` are not taken as header bytes.
-        uint64_t w;
-        __builtin_memcpy(&w, base + pos, 8);
-        const uint32_t avail = min(5u, ids_end - pos);
+    // the segment state is the same in every lane: keep it in scalar registers
+    uint32_t dpos = __builtin_amdgcn_readfirstlane(seg.x), o = __builtin_amdgcn_readfirstlane(seg.y);
+    uint32_t cnt = __builtin_amdgcn_readfirstlane(seg.z);
+    const uint32_t sw = __builtin_amdgcn_readfirstlane(seg.w);
+    bool packed = sw & 1u;
+    uint32_t val = sw >> 1;
+    while (true) {
+        const uint32_t lo = max(o, tile_start), hi = min(o + cnt, tile_end);
+        uint32_t next;
+        if (packed) {
+            if (lo < hi) {
+                // bytes holding rows [lo, hi) of this segment; at most kRleTile * 16 bits, well inside a window
+                const uint32_t b0 = dpos + (((lo - o) * bw) >> 3);
+                const uint32_t b1 = dpos + (((hi - o) * bw + 7) >> 3);
+                w.need(b0, b1 - b0 + 8);
+#pragma unroll 4
+                for (uint32_t i = lo + lane; i < hi; i += 64) ids[i - tile_start] = (uint16_t)w.bits(dpos, (i - o) * bw, bw);
+            }
+            next = dpos + ((cnt + 7) >> 3) * bw;
+        } else {
+            for (uint32_t i = lo + lane; i < hi; i += 64) ids[i - tile_start] = (uint16_t)val;
+            next = dpos;
+        }
+        o += cnt;
+        if (o >= tile_end || next >= ids_end) break;
+        // next segment header: uvarint (<= 5 bytes, none at or beyond ids_end), then a run's value
+        w.need(next, 16);
+        const uint64_t word = w.peek64u(next);
+        const uint32_t avail = min(5u, ids_end - next);
         uint32_t h = 0, nb = 0;
         bool open = true;
 #pragma unroll
         for (uint32_t i = 0; i < 5; i++) {
-            const uint32_t b = (uint32_t)(w >> (8 * i)) & 0xFFu;
+            const uint32_t b = (uint32_t)(word >> (8 * i)) & 0xFFu;
             const bool take = open && i < avail;
             if (take) { h |= (b & 0x7F) << (7 * i); nb = i + 1; }
             open = take && (b & 0x80);
         }
-        pos += nb;
-        const uint32_t cnt = h >> 1;
-        const uint32_t lo = max(o, tile_start), hi = min(o + cnt, tile_end);
-        if (h & 1) {
-            const uint8_t* data = base + pos;
-#pragma unroll 4
-            for (uint32_t i = lo + lane; i < hi; i += 64) ids[i - tile_start] = (uint16_t)extract32(data, (i - o) * bw, bw);
-            pos += ((cnt + 7) >> 3) * bw;
-        } else {
-            const uint32_t val = (uint32_t)(w >> (8 * nb)) & ((1u << (8 * bytew)) - 1u);  // bytew is 0..2
-            for (uint32_t i = lo + lane; i < hi; i += 64) ids[i - tile_start] = (uint16_t)val;
-            pos += bytew;
+        cnt = h >> 1;
+        packed = h & 1u;
+        dpos = next + nb;
+        if (!packed) {
+            val = (uint32_t)(word >> (8 * nb)) & ((1u << (8 * bytew)) - 1u);  // bytew is 0..2
+            dpos += bytew;
         }
-        o += cnt;
     }
-    // the tile's ids were written by this wave only; make them visible to all its lanes
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // the tile's ids were written by this wave only and are read by this wave only
+    Win::wave_lds_sync();
 }
 
 // Common prologue of the tile kernels: which pack / tile this wave owns. Returns false when there is nothing to do.
@@ -531,16 +678,18 @@ __global__ __launch_bounds__(256) void k_dict_num(const DevPack* __restrict__ pa
                                                   PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                   uint8_t* __restrict__ out, const uint8_t* __restrict__ scratch) {
     __shared__ uint16_t s_ids[4][kRleTile];
+    __shared__ __align__(16) uint8_t s_win[4][kWinAlloc];
     TileCtx t;
     if (!tile_ctx(t, packs, list, metas, K_DICT_NUM, 0)) return;
     const DevPack& P = packs[t.pi];
     const PackMeta& M = metas[t.pi];
-    const uint8_t* base = in + P.in_off;
     const U* __restrict__ dict = (const U*)(scratch + P.s_dict);
     U* __restrict__ dst = (U*)(out + P.out_off) + t.tile_start;
     uint16_t* ids = s_ids[threadIdx.x >> 6];
-    const uint2 restart = ((const uint2*)(scratch + P.s_restart))[t.tile];
-    rle_tile_expand(base, M.id_bw, M.ids_off + 4 + M.ids_len, restart, t.tile_start, t.tile_end, ids);
+    const uint4 seg = ((const uint4*)(scratch + P.s_restart))[t.tile];
+    Win w;
+    w.init(in + P.in_off, (uint32_t)P.pack_size, s_win[threadIdx.x >> 6]);
+    rle_tile_expand(w, M.id_bw, M.ids_off + 4 + M.ids_len, seg, t.tile_start, t.tile_end, ids);
     const uint32_t cnt = t.tile_end - t.tile_start, lane = threadIdx.x & 63;
     // a lane takes two neighbouring rows of every 128: ids come out of LDS two at a time, results leave as 8 / 16 byte
     // stores, and the 16 gathers are all in flight before the first store
@@ -947,46 +1096,6 @@ __global__ __launch_bounds__(256) void k_front_decode(const DevPack* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_str_rows: string dictionary packs, one wave per tile of kRleTile rows: expand ids, look up each row's dictionary
-// slice; writes the row length into the output index (slot i+1, scanned in place by k_row_scan) and the slice start
-// into scratch.  (DictStruct.decodeStrings, DictStruct.java:97-110.)
-// ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_str_rows(const DevPack* __restrict__ packs, const int* __restrict__ list,
-                                                  PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
-                                                  uint8_t* __restrict__ out, uint8_t* __restrict__ scratch) {
-    __shared__ uint16_t s_ids[4][kRleTile];
-    TileCtx t;
-    if (!tile_ctx(t, packs, list, metas, K_DICT_STR, 0)) return;
-    const DevPack& P = packs[t.pi];
-    const PackMeta& M = metas[t.pi];
-    const uint8_t* base = in + P.in_off;
-    const uint32_t* __restrict__ doff = (const uint32_t*)(scratch + P.s_dict);
-    uint32_t* __restrict__ rowlen = (uint32_t*)(out + P.out_off) + 1 + t.tile_start;
-    uint32_t* __restrict__ srcoff = (uint32_t*)(scratch + P.s_rows) + t.tile_start;
-    uint16_t* ids = s_ids[threadIdx.x >> 6];
-    const uint2 restart = ((const uint2*)(scratch + P.s_restart))[t.tile];
-    rle_tile_expand(base, M.id_bw, M.ids_off + 4 + M.ids_len, restart, t.tile_start, t.tile_end, ids);
-    const uint32_t cnt = t.tile_end - t.tile_start, lane = threadIdx.x & 63;
-    uint32_t id[16];
-    bool bad = false;
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const uint32_t r = q * 64 + lane;
-        id[q] = r < cnt ? ids[r] : 0u;
-        if (id[q] >= t.ec) { bad = true; id[q] = 0; }
-    }
-    uint2 ab[16];
-#pragma unroll
-    for (int q = 0; q < 16; q++) __builtin_memcpy(&ab[q], doff + id[q], 8);  // doff[id], doff[id + 1]
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const uint32_t r = q * 64 + lane;
-        if (r < cnt) { rowlen[r] = ab[q].y - ab[q].x; srcoff[r] = ab[q].x; }
-    }
-    if (bad) metas[t.pi].status = E_CORRUPT;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // k_row_scan: one workgroup per string dictionary pack: turns the row lengths in the output index into offsets
 // (offset[0] = 0, offset[i+1] = offset[i] + len[i]; StringsStruct.Builder, StringsStruct.java:120-158), checks that the
 // body fits the output.
@@ -1030,13 +1139,13 @@ __global__ __launch_bounds__(256) void k_row_scan(const DevPack* __restrict__ pa
 // rounds with a running total.  Writes the output index (offset[0] = 0, offset[i+1] = offset[i] + len[i];
 // StringsStruct.Builder, StringsStruct.java:120-158) and each row's slice start into scratch, checks that the body fits,
 // zero-fills what the body leaves of dpn.dataSize.  (DictStruct.decodeStrings, DictStruct.java:97-110.)
-// Does in one pass what k_str_rows + k_row_scan do in two.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_str_index(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                     PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ scratch) {
     constexpr int kWaves = 16;
     __shared__ uint16_t s_ids[kWaves][kRleTile];
+    __shared__ __align__(16) uint8_t s_win[kWaves][kWinAlloc];
     __shared__ uint32_t s_wsum[2][kWaves];
     __shared__ unsigned long long s_tot;
     const int pi = list[blockIdx.x];
@@ -1051,7 +1160,9 @@ __global__ __launch_bounds__(1024) void k_str_index(const DevPack* __restrict__ 
     const uint32_t* __restrict__ doff = (const uint32_t*)(scratch + P.s_dict);
     uint32_t* __restrict__ off = (uint32_t*)(out + P.out_off);
     uint32_t* __restrict__ srcoff = (uint32_t*)(scratch + P.s_rows);
-    const uint2* restarts = (const uint2*)(scratch + P.s_restart);
+    const uint4* restarts = (const uint4*)(scratch + P.s_restart);
+    Win w;
+    w.init(base, (uint32_t)P.pack_size, s_win[wave]);
     const uint32_t id_bw = M.id_bw, ids_end = M.ids_off + 4 + M.ids_len;
     uint16_t* ids = s_ids[wave];
     __shared__ int s_bad;
@@ -1064,7 +1175,7 @@ __global__ __launch_bounds__(1024) void k_str_index(const DevPack* __restrict__ 
         const uint32_t tile = t0 + wave;
         const uint32_t tile_start = min(tile * (uint32_t)kRleTile, n), tile_end = min(n, tile_start + (uint32_t)kRleTile);
         const uint32_t cnt = tile_end - tile_start;  // 0 for waves past the last tile
-        if (cnt) rle_tile_expand(base, id_bw, ids_end, restarts[tile], tile_start, tile_end, ids);
+        if (cnt) rle_tile_expand(w, id_bw, ids_end, restarts[tile], tile_start, tile_end, ids);
         uint2 ab[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) {
@@ -1245,6 +1356,7 @@ __global__ __launch_bounds__(256) void k_dict_struct(const DevPack* __restrict__
                                                      PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                      uint8_t* __restrict__ out, const uint8_t* __restrict__ scratch) {
     __shared__ uint16_t s_ids[4][kRleTile];
+    __shared__ __align__(16) uint8_t s_win[4][kWinAlloc];
     const int pi = list[blockIdx.y];
     const PackMeta& M = metas[pi];
     if (M.status < 0 || (M.kind != K_DICT_NUM && M.kind != K_DICT_STR) || M.dict_struct_size == 0) return;
@@ -1279,9 +1391,11 @@ __global__ __launch_bounds__(256) void k_dict_struct(const DevPack* __restrict__
     const uint32_t tile_end = min(n, tile_start + (uint32_t)kRleTile);
     uint8_t* idp = ds + 4 + dict_size + 4 + 4ull * tile_start;
     const bool aligned = (((uintptr_t)idp) & 3) == 0;
-    const uint2 restart = ((const uint2*)(scratch + P.s_restart))[tile];
+    const uint4 seg = ((const uint4*)(scratch + P.s_restart))[tile];
     uint16_t* ids = s_ids[threadIdx.x >> 6];
-    rle_tile_expand(in + P.in_off, M.id_bw, M.ids_off + 4 + M.ids_len, restart, tile_start, tile_end, ids);
+    Win w;
+    w.init(in + P.in_off, (uint32_t)P.pack_size, s_win[threadIdx.x >> 6]);
+    rle_tile_expand(w, M.id_bw, M.ids_off + 4 + M.ids_len, seg, tile_start, tile_end, ids);
     const uint32_t cnt = tile_end - tile_start;
     for (uint32_t r = threadIdx.x & 63; r < cnt; r += 64) {
         const uint32_t id = ids[r];
@@ -1398,7 +1512,7 @@ static inline unsigned cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
 void launch_parse(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_parse, dim3(cdiv((unsigned)count * 4, 256)), dim3(256), 0, c.stream, c.packs, list, count, c.metas,
+    hipLaunchKernelGGL(k_parse, dim3((unsigned)count), dim3(256), 0, c.stream, c.packs, list, count, c.metas,
                        c.in, c.scratch);
 }
 void launch_delta(const LaunchCtx& c, const int* list, int count, int width, int streams) {
@@ -1445,11 +1559,6 @@ void launch_front_decode(const LaunchCtx& c, const int* list, int count, int use
     if (count <= 0) return;
     hipLaunchKernelGGL(k_front_decode, dim3(64, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch,
                        (const uint8_t*)c.scratch, use_ds);
-}
-void launch_str_rows(const LaunchCtx& c, const int* list, int count) {
-    if (count <= 0) return;
-    hipLaunchKernelGGL(k_str_rows, dim3(IXR_PACK_TILES / 4, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out,
-                       c.scratch);
 }
 void launch_str_index(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;

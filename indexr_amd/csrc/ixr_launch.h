@@ -29,7 +29,6 @@ void launch_front_serial(const LaunchCtx& c, const int* list, int count);
 void launch_front_summary(const LaunchCtx& c, const int* list, int count, int use_ds);
 void launch_front_combine(const LaunchCtx& c, const int* list, int count, int use_ds);
 void launch_front_decode(const LaunchCtx& c, const int* list, int count, int use_ds);
-void launch_str_rows(const LaunchCtx& c, const int* list, int count);
 void launch_row_scan(const LaunchCtx& c, const int* list, int count);
 void launch_str_index(const LaunchCtx& c, const int* list, int count);
 void launch_str_copy(const LaunchCtx& c, const int* list, int count);
