@@ -28,7 +28,7 @@
 namespace ixr {
 
 // error codes (mirror include/ixr_gpu.h)
-constexpr int32_t E_OVERFLOW = -1, E_CORRUPT = -2, E_ILLEGAL_ENC = -101, E_UNSUPPORTED = -102;
+constexpr int32_t E_OVERFLOW = -1, E_CORRUPT = -2, E_ILLEGAL_ENC = -101;
 
 // ---------------------------------------------------------------------------------------------------------------
 // unaligned little-endian access built from aligned dword loads (the arena is readable 16 bytes past every pack)
@@ -75,6 +75,7 @@ __device__ __forceinline__ uint32_t bit_width32(uint32_t v) { return v ? 32u - (
 // headers) from there.  One coalesced global load fills the window; every step of a serial walk then costs an LDS round
 // trip instead of a trip to L2/HBM.  All lanes of the wave call these functions with the same arguments.
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int kParseLaneThreshold = 16384;  // packs per launch from which k_parse_lanes is used
 constexpr uint32_t kWin = 4096;
 constexpr uint32_t kWinAlloc = kWin + 16;  // bytes of LDS per window (16 spare bytes so that 12-byte peeks never run off)
 
@@ -289,29 +290,20 @@ __device__ int32_t walk_rle(Win& w, uint32_t off, uint32_t len, uint32_t n, uint
     return err;
 }
 
-__global__ __launch_bounds__(256) void k_parse(const DevPack* __restrict__ packs, const int* __restrict__ list, int count,
-                                               PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
-                                               uint8_t* __restrict__ scratch) {
-    __shared__ __align__(16) uint8_t s_win[3][kWinAlloc];
-    __shared__ int32_t s_werr[4];
-    __shared__ int64_t s_first[2];
-    const int k = threadIdx.x >> 6;  // wave = stream
-    const int pi = list[blockIdx.x];
-    const DevPack P = packs[pi];
-    const uint8_t* base = in + P.in_off;
+// What a pack is, from its descriptor and fixed-position header fields: kind, dictionary geometry, where its serial
+// streams start (PackCompressor_VLT.decompress dispatch :130-170, DictStructUtil.decompress :83-142, DeltaCodec.decodeStrings
+// :355-366).  `consumed` is the number of bytes the pack's framing claims.
+__device__ __forceinline__ void pack_header(const DevPack& P, const uint8_t* base, PackMeta& m, int32_t& err, int64_t& consumed,
+                                            bool& has_ids) {
     const uint32_t psz = (uint32_t)P.pack_size;
     const uint32_t n = (uint32_t)P.obj_count;
     const int W = P.width;  // 32, 64 or 0 (strings)
-    (void)count;
-
-    // every wave derives the pack's header fields (a few uniform loads); wave 0 publishes them
-    PackMeta m;
     m.status = 0; m.kind = K_NONE; m.entry_count = 0; m.id_bw = 0; m.ids_off = 0; m.ids_len = 0; m.entries_off = 0;
     m.entries_plain = 0; m.sfx_off = 0; m.sfx_len = 0; m.dict_struct_size = 0; m.max_len = 0; m.front_blocks = 0; m.front_stride = 0;
     m.s[0].n = m.s[1].n = 0; m.s[0].in_off = m.s[1].in_off = 0; m.s[0].first = m.s[1].first = 0;
-    int32_t err = 0;
-    int64_t consumed = 0;
-    bool has_ids = false;
+    err = 0;
+    consumed = 0;
+    has_ids = false;
 
     auto rd32 = [&](uint64_t off) -> uint32_t {  // bounds-checked header read
         if (off + 4 > psz) { if (!err) err = E_CORRUPT; return 0; }
@@ -425,6 +417,168 @@ __global__ __launch_bounds__(256) void k_parse(const DevPack* __restrict__ packs
         }
     }
     if (!err && (consumed < 0 || consumed > (int64_t)psz)) err = E_CORRUPT;
+
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_parse_lanes: the same walk with one LANE per stream (4 lanes per pack), reading the framing bytes straight from
+// global memory.  Every step of a chain pays a memory round trip, but a launch over tens of thousands of packs keeps
+// hundreds of thousands of independent chains in flight, which wins over the window version's faster steps once the
+// chip is oversubscribed with walker waves.  The launcher picks by batch size.
+// ---------------------------------------------------------------------------------------------------------------
+struct Walker {
+    const uint8_t* base;  // pack start
+    uint32_t pos;         // current offset in the pack
+    uint32_t end;         // one past the last readable offset of the current stream
+    int32_t err;
+    __device__ __forceinline__ uint32_t u8() {
+        if (pos >= end) { err = E_CORRUPT; return 0; }
+        return base[pos++];
+    }
+    // VarInteger.readUnsignedVarInt / readUnsignedVarLong (VarInteger.java:68-96); at most 5 / 10 bytes
+    __device__ __forceinline__ uint64_t uvarint(int max_bytes) {
+        uint64_t v = 0;
+        int shift = 0;
+        for (int i = 0; i < max_bytes; i++) {
+            uint32_t b = u8();
+            v |= (uint64_t)(b & 0x7F) << shift;
+            if (!(b & 0x80)) return v;
+            shift += 7;
+        }
+        err = E_CORRUPT;
+        return v;
+    }
+};
+
+
+// Walk one DELTA stream (DeltaCodec.decodeInts/decodeLongs framing, DeltaCodec.java:100-141, 204-245) and write its index.
+__device__ int32_t lane_walk_delta(const uint8_t* base, uint32_t pack_size, uint32_t off, uint32_t n, int width,
+                              int64_t* min_delta, uint32_t* mb, int64_t* first_out, bool write) {
+    Walker w{base, off, pack_size, 0};
+    if (off + 4 > pack_size) return E_CORRUPT;
+    int32_t len = (int32_t)ld32u(base + off);
+    if (len < 0 || (uint64_t)off + 4 + (uint64_t)len > pack_size) return E_CORRUPT;
+    w.pos = off + 4;
+    w.end = off + 4 + (uint32_t)len;
+    const int vb = width == 32 ? 5 : 10;
+    uint64_t raw = w.uvarint(vb);
+    *first_out = width == 32 ? unzigzag32(raw) : unzigzag64(raw);
+    uint32_t nb = (n + kBlock - 1) / kBlock;
+    for (uint32_t b = 0; b < nb && !w.err; b++) {
+        raw = w.uvarint(vb);
+        int64_t md = width == 32 ? unzigzag32(raw) : unzigzag64(raw);
+        if (write) min_delta[b] = md;
+        uint32_t cnt = min((uint32_t)kBlock, n - b * kBlock);
+        for (uint32_t m = 0; m * kMini < cnt; m++) {
+            uint32_t c = min((uint32_t)kMini, cnt - m * kMini);
+            uint32_t bw = w.u8();
+            if (bw > (uint32_t)width) w.err = E_CORRUPT;
+            if (w.err) break;
+            if (w.pos >= (1u << 24)) { w.err = E_CORRUPT; break; }
+            if (write) mb[b * 4 + m] = w.pos | (bw << 24);
+            w.pos += ((c + 7) >> 3) * bw;
+            if (w.pos > w.end) { w.err = E_CORRUPT; break; }
+        }
+    }
+    if (!w.err && w.pos != w.end) w.err = E_CORRUPT;
+    return w.err;
+}
+
+// Walk the RLE/bit-packing hybrid id stream (RLEPackingHybridCodec.decodeInts, RLEPackingHybridCodec.java:97-128) and
+// record, for every tile of kRleTile rows, the segment header that covers the tile's first row.
+__device__ int32_t lane_walk_rle(const uint8_t* base, uint32_t off, uint32_t len, uint32_t n, uint32_t bw, uint4* restart, bool write) {
+    Walker w{base, off + 4, off + 4 + len, 0};
+    const uint32_t bytew = (bw + 7) >> 3;
+    uint32_t o = 0, next_tile = 0;
+    while (w.pos < w.end) {
+        uint32_t h = (uint32_t)w.uvarint(5);
+        if (w.err) break;
+        uint32_t cnt = h >> 1;
+        uint64_t payload = (h & 1) ? (uint64_t)((cnt + 7) >> 3) * bw : bytew;
+        if ((uint64_t)w.pos + payload > w.end || cnt > n - o) { w.err = E_CORRUPT; break; }
+        if (cnt && next_tile * (uint32_t)kRleTile < o + cnt) {
+            uint32_t val = 0;
+            if (!(h & 1)) for (uint32_t k = 0; k < bytew; k++) val |= (uint32_t)base[w.pos + k] << (8 * k);
+            const uint4 rec = make_uint4((h & 1) ? w.pos : w.pos + bytew, o, cnt, (h & 1) ? 1u : (val << 1));
+            while (next_tile * (uint32_t)kRleTile < o + cnt) {
+                if (write) restart[next_tile] = rec;
+                next_tile++;
+            }
+        }
+        o += cnt;
+        w.pos += (uint32_t)payload;
+    }
+    if (!w.err && o != n) w.err = E_CORRUPT;  // Preconditions.checkState(valIndex == valCount) :126
+    return w.err;
+}
+
+__global__ __launch_bounds__(256) void k_parse_lanes(const DevPack* __restrict__ packs, const int* __restrict__ list, int count,
+                                                     PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
+                                                     uint8_t* __restrict__ scratch) {
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    int li = tid >> 2;
+    const int k = tid & 3;
+    const bool active = li < count;
+    if (!active) li = count - 1;  // keep the lane alive for the shuffles below; its writes are suppressed
+    const int pi = list[li];
+    const DevPack P = packs[pi];
+    const uint8_t* base = in + P.in_off;
+    const uint32_t psz = (uint32_t)P.pack_size;
+    const uint32_t n = (uint32_t)P.obj_count;
+    const int W = P.width;
+    PackMeta m;
+    int32_t err;
+    int64_t consumed;
+    bool has_ids;
+    pack_header(P, base, m, err, consumed, has_ids);
+
+    int32_t werr = 0;
+    int64_t first = 0;
+    if (!err) {
+        const StreamDesc sd = k == 0 ? m.s[0] : m.s[1];
+        if (k < 2 && sd.n) {
+            int64_t* md = (int64_t*)(scratch + (k == 0 ? P.s_idx[0] : P.s_idx[1]));
+            uint32_t* mb = (uint32_t*)(md + (P.obj_count + kBlock - 1) / kBlock);
+            werr = lane_walk_delta(base, psz, sd.in_off, sd.n, W ? W : 32, md, mb, &first, active);
+        } else if (k == 2 && has_ids) {
+            werr = lane_walk_rle(base, m.ids_off, m.ids_len, n, m.id_bw, (uint4*)(scratch + P.s_restart), active);
+        }
+    }
+    // lane 0 of each group of 4 collects the results and writes the meta record
+    const int lane = threadIdx.x & 63;
+    const int g0 = lane & ~3;
+    int32_t e0 = __shfl(werr, g0), e1 = __shfl(werr, g0 + 1), e2 = __shfl(werr, g0 + 2);
+    int64_t f1 = __shfl(first, g0 + 1);
+    if (active && k == 0) {
+        m.s[0].first = first;
+        m.s[1].first = f1;
+        if (!err) err = e0 ? e0 : (e1 ? e1 : e2);
+        m.status = err ? err : (int32_t)consumed;
+        metas[pi] = m;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_parse(const DevPack* __restrict__ packs, const int* __restrict__ list, int count,
+                                               PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
+                                               uint8_t* __restrict__ scratch) {
+    __shared__ __align__(16) uint8_t s_win[3][kWinAlloc];
+    __shared__ int32_t s_werr[4];
+    __shared__ int64_t s_first[2];
+    const int k = threadIdx.x >> 6;  // wave = stream
+    const int pi = list[blockIdx.x];
+    const DevPack P = packs[pi];
+    const uint8_t* base = in + P.in_off;
+    const uint32_t psz = (uint32_t)P.pack_size;
+    const uint32_t n = (uint32_t)P.obj_count;
+    const int W = P.width;  // 32, 64 or 0 (strings)
+    (void)count;
+
+    // every wave derives the pack's header fields (a few uniform loads); wave 0 publishes them
+    PackMeta m;
+    int32_t err;
+    int64_t consumed;
+    bool has_ids;
+    pack_header(P, base, m, err, consumed, has_ids);
 
     // ---- the serial walks, one per wave
     int32_t werr = 0;
@@ -707,11 +861,21 @@ __global__ __launch_bounds__(256) void k_dict_num(const DevPack* __restrict__ pa
     U v[16];
 #pragma unroll
     for (int q = 0; q < 16; q++) v[q] = dict[id[q]];
-    struct alignas(2 * sizeof(U)) Pair { U a, b; };
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         const uint32_t r = q * 128 + 2 * lane;
-        if (r + 1 < cnt) *(Pair*)(dst + r) = Pair{v[2 * q], v[2 * q + 1]};
+        // streaming (non-temporal) stores: the rows are not read again here and must not push the dictionary out of L2
+        if (r + 1 < cnt) {
+            if constexpr (sizeof(U) == 4) {
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                u32x2 t = {(uint32_t)v[2 * q], (uint32_t)v[2 * q + 1]};
+                __builtin_nontemporal_store(t, (u32x2*)(dst + r));
+            } else {
+                typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+                u64x2 t = {(uint64_t)v[2 * q], (uint64_t)v[2 * q + 1]};
+                __builtin_nontemporal_store(t, (u64x2*)(dst + r));
+            }
+        }
         else if (r < cnt) dst[r] = v[2 * q];
     }
     if (bad) metas[t.pi].status = E_CORRUPT;
@@ -1243,6 +1407,13 @@ __device__ __forceinline__ uint4 ld16u(const uint8_t* p) {
     __builtin_memcpy(&v, p, 16);
     return v;
 }
+// 16-byte aligned streaming store: decoded rows are written once and not read again by the decoder, a non-temporal store
+// keeps them from displacing the dictionaries in L2
+__device__ __forceinline__ void st16_stream(uint8_t* p, uint4 w) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 t = {w.x, w.y, w.z, w.w};
+    __builtin_nontemporal_store(t, (u32x4*)p);
+}
 // 64-bit mask with the low 8*x bits set, x clamped to 0..8
 __device__ __forceinline__ uint64_t low_bytes(int x) {
     x = max(x, 0);
@@ -1281,22 +1452,16 @@ __global__ __launch_bounds__(256) void k_str_copy(const DevPack* __restrict__ pa
     if (b1 <= b0) return;
     const uint8_t* dbody16 = dbody - 16;  // chunk byte k of row r comes from dbody16[s_dlt[r] + cpos + k]; the sum is >= 1
 
-#ifdef IXR_ABL_NOLOAD
-#define IXR_LD16(p, c) make_uint4((uint32_t)(uintptr_t)(p), c, c, c)
-#else
-#define IXR_LD16(p, c) ld16u(p)
-#endif
     // One 16-byte chunk: finish it given the row `r` of its first byte; handles chunks that straddle rows.
     auto finish = [&](uint32_t cpos, uint32_t first, uint32_t cend, uint32_t r, uint4 w) {
         uint32_t rend = s_off[r + 1];
         uint32_t pos = min(cend, rend);
-#ifndef IXR_ABL_NOSTRADDLE
         if (pos < cend) {
             uint64_t wl = (uint64_t)w.x | ((uint64_t)w.y << 32), wh = (uint64_t)w.z | ((uint64_t)w.w << 32);
             while (pos < cend) {
                 do { r++; rend = s_off[r + 1]; } while (rend <= pos && r + 1 < rows);  // next row that is not empty
                 const uint32_t segend = min(cend, max(rend, pos + 1));
-                const uint4 v = IXR_LD16(dbody16 + (uint32_t)(s_dlt[r] + cpos), cpos);
+                const uint4 v = ld16u(dbody16 + (uint32_t)(s_dlt[r] + cpos));
                 const int a = (int)(pos - cpos), e = (int)(segend - cpos);
                 const uint64_t ml = low_bytes(e) & ~low_bytes(a), mh = low_bytes(e - 8) & ~low_bytes(a - 8);
                 wl = (wl & ~ml) | (((uint64_t)v.x | ((uint64_t)v.y << 32)) & ml);
@@ -1305,9 +1470,8 @@ __global__ __launch_bounds__(256) void k_str_copy(const DevPack* __restrict__ pa
             }
             w = make_uint4((uint32_t)wl, (uint32_t)(wl >> 32), (uint32_t)wh, (uint32_t)(wh >> 32));
         }
-#endif
         if (first == cpos && cend == cpos + 16u) {
-            *(uint4*)(base16 + cpos) = w;
+            st16_stream(base16 + cpos, w);
         } else {
             const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
@@ -1327,10 +1491,6 @@ __global__ __launch_bounds__(256) void k_str_copy(const DevPack* __restrict__ pa
         const uint32_t fB = hasB ? cB : fA, eB = min(cB + 16u, b1);
         // largest r in [0, rows) with s_off[r] <= first: s_off[0] = b0 <= first < b1 = s_off[rows]
         uint32_t rA = 0, rB = 0;
-#ifdef IXR_ABL_NOSEARCH
-        rA = min(rows - 1, (uint32_t)(((uint64_t)(fA - b0) * rows) / (b1 - b0)));
-        rB = min(rows - 1, (uint32_t)(((uint64_t)(fB - b0) * rows) / (b1 - b0)));
-#else
 #pragma unroll
         for (uint32_t step = kStrTileRows / 2; step >= 1; step >>= 1) {
             const uint32_t ca = rA + step, cb = rB + step;
@@ -1338,9 +1498,8 @@ __global__ __launch_bounds__(256) void k_str_copy(const DevPack* __restrict__ pa
             if (ca < rows && oa <= fA) rA = ca;
             if (cb < rows && ob <= fB) rB = cb;
         }
-#endif
-        const uint4 wA = IXR_LD16(dbody16 + (uint32_t)(s_dlt[rA] + cA), cA);
-        const uint4 wB = IXR_LD16(dbody16 + (uint32_t)(s_dlt[rB] + (hasB ? cB : cA)), cB);
+        const uint4 wA = ld16u(dbody16 + (uint32_t)(s_dlt[rA] + cA));
+        const uint4 wB = ld16u(dbody16 + (uint32_t)(s_dlt[rB] + (hasB ? cB : cA)));
         finish(cA, fA, eA, rA, wA);
         if (hasB) finish(cB, fB, eB, rB, wB);
     }
@@ -1512,6 +1671,12 @@ static inline unsigned cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
 void launch_parse(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;
+    // below this many packs the chip is not full of walker waves and the faster steps of the window version win
+    if (count >= kParseLaneThreshold) {
+        hipLaunchKernelGGL(k_parse_lanes, dim3(cdiv((unsigned)count * 4, 256)), dim3(256), 0, c.stream, c.packs, list, count, c.metas,
+                           c.in, c.scratch);
+        return;
+    }
     hipLaunchKernelGGL(k_parse, dim3((unsigned)count), dim3(256), 0, c.stream, c.packs, list, count, c.metas,
                        c.in, c.scratch);
 }

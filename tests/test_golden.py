@@ -70,3 +70,17 @@ def test_gpu_decodes_golden():
         out, consumed = L.decode_pack(pack, c["data_type"], c["encode_type"], c["n"], len(data))
         assert consumed == len(pack), c["name"]
         assert np.array_equal(np.asarray(out, dtype=np.uint8), data), c["name"]
+
+
+@pytest.mark.gpu
+def test_gpu_decodes_golden_in_a_very_large_batch():
+    """Batches of 16384 packs and more take the lane-per-stream framing walk instead of the LDS-window one; the golden
+    packs repeated 530 times (16430 packs) must decode identically through it."""
+    import gpu_util as G
+    cases = []
+    for rep in range(530):
+        for c in CASES:
+            cases.append(G.Case(_b(c, "pack"), c["data_type"], c["encode_type"], c["n"], len(_b(c, "data")), expect=_b(c, "data"),
+                                name="%s#%d" % (c["name"], rep)))
+    assert len(cases) >= 16384
+    G.check_cases(cases)
