@@ -150,6 +150,11 @@ struct ixr_plan {
     size_t event_used = 0;
     std::vector<std::pair<std::string, KernelStat>> stats;
     int all_off = 0;  // offset of the identity list (all packs) in d_lists
+    // The numeric and the string kernels of a group touch disjoint packs and disjoint scratch; they run on two streams
+    // so that the latency-bound string kernels overlap the bandwidth-bound numeric ones.  `aux` forks off the caller's
+    // stream at the start of every group and joins it at the end (events), so the caller still sees one ordered stream.
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 // Lays the scratch regions of one pack out from obj_count / data_size alone.  Two areas:
@@ -195,6 +200,9 @@ extern "C" void ixr_plan_destroy(ixr_plan* plan) {
     if (plan->d_lists) (void)hipFree(plan->d_lists);
     if (plan->d_scratch) (void)hipFree(plan->d_scratch);
     for (hipEvent_t e : plan->event_pool) (void)hipEventDestroy(e);
+    if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
+    if (plan->ev_join) (void)hipEventDestroy(plan->ev_join);
+    if (plan->aux) (void)hipStreamDestroy(plan->aux);
     delete plan;
 }
 
@@ -276,6 +284,13 @@ static ixr_plan* plan_create(int32_t device, const ixr_pack_desc* descs, int32_t
         ixr_plan_destroy(pl);
         return nullptr;
     }
+    if ((e = hipStreamCreateWithFlags(&pl->aux, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming)) != hipSuccess) {
+        fail(IXR_ERR_HIP, "creating the plan's auxiliary stream failed: %s", hipGetErrorString(e));
+        ixr_plan_destroy(pl);
+        return nullptr;
+    }
     if ((e = hipMemcpy(pl->d_packs, pl->hpacks.data(), sizeof(DevPack) * (size_t)n_packs, hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(pl->d_lists, lists.data(), sizeof(int) * lists.size(), hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemset(pl->d_metas, 0, sizeof(PackMeta) * (size_t)n_packs)) != hipSuccess) {
@@ -347,11 +362,15 @@ int32_t check_run_args(ixr_plan* pl, const void* d_in, uint64_t in_bytes, void* 
 void run_parse_all(ixr_plan* pl, Timer& T, LaunchCtx& c) {
     T.run("k_parse", pl->n, [&] { launch_parse(c, pl->d_lists + pl->all_off, pl->n); });
 }
-// dictionary construction of one group; shared by the row decode and the DictStruct run
-void run_group_front(ixr_plan* pl, Timer& T, LaunchCtx& c, const Group& g, int use_ds) {
+// dictionary construction of one group, numeric packs: DELTA rows and delta-coded dictionary entries
+void run_group_front_num(ixr_plan* pl, Timer& T, LaunchCtx& c, const Group& g) {
     const int* L = pl->d_lists;
     T.run("k_delta<u32>", g.cnt[L_N32], [&] { launch_delta(c, L + g.off[L_N32], g.cnt[L_N32], 32, 1); });
     T.run("k_delta<u64>", g.cnt[L_N64], [&] { launch_delta(c, L + g.off[L_N64], g.cnt[L_N64], 64, 1); });
+}
+// dictionary construction of one group, string packs: length lists, offsets, front-coded bodies
+void run_group_front_str(ixr_plan* pl, Timer& T, LaunchCtx& c, const Group& g, int use_ds) {
+    const int* L = pl->d_lists;
     T.run("k_delta<u32>(str lens)", g.cnt[L_STR], [&] { launch_delta(c, L + g.off[L_STR], g.cnt[L_STR], 32, 2); });
     T.run("k_str_dict_scan", g.cnt[L_STR], [&] { launch_str_dict_scan(c, L + g.off[L_STR], g.cnt[L_STR]); });
     T.run("k_front_summary", g.cnt[L_STR], [&] { launch_front_summary(c, L + g.off[L_STR], g.cnt[L_STR], use_ds); });
@@ -368,17 +387,31 @@ extern "C" int32_t ixr_plan_run(ixr_plan* pl, const void* d_in, uint64_t in_byte
     hipStream_t st = (hipStream_t)stream;
     // Timed launches accumulate over successive runs until ixr_plan_status collects them (bounded, in case nobody does).
     if (pl->timed.size() > 200000) { pl->timed.clear(); pl->event_used = 0; }
-    Timer T{pl, st};
+    Timer T{pl, st}, TB{pl, pl->aux};
     LaunchCtx c{st, pl->d_packs, pl->d_metas, (const uint8_t*)d_in, (uint8_t*)d_out, pl->d_scratch};
+    LaunchCtx cb = c;
+    cb.stream = pl->aux;
     const int* L = pl->d_lists;
     run_parse_all(pl, T, c);
     for (const Group& g : pl->groups) {
-        run_group_front(pl, T, c, g, 0);
-        T.run("k_dict_num<u32>", g.cnt[L_N32], [&] { launch_dict_num(c, L + g.off[L_N32], g.cnt[L_N32], 32); });
-        T.run("k_dict_num<u64>", g.cnt[L_N64], [&] { launch_dict_num(c, L + g.off[L_N64], g.cnt[L_N64], 64); });
-        T.run("k_copy_raw", g.cnt[L_RAW], [&] { launch_copy_raw(c, L + g.off[L_RAW], g.cnt[L_RAW]); });
+        const bool fork = g.cnt[L_STR] > 0 && (g.cnt[L_N32] + g.cnt[L_N64] + g.cnt[L_RAW]) > 0;
+        LaunchCtx& cn = fork ? cb : c;  // numeric kernels: on the auxiliary stream when there is string work to overlap
+        Timer& TN = fork ? TB : T;
+        if (fork) {
+            HIP_TRY(hipEventRecord(pl->ev_fork, st), return IXR_ERR_HIP);
+            HIP_TRY(hipStreamWaitEvent(pl->aux, pl->ev_fork, 0), return IXR_ERR_HIP);
+        }
+        run_group_front_num(pl, TN, cn, g);
+        TN.run("k_dict_num<u32>", g.cnt[L_N32], [&] { launch_dict_num(cn, L + g.off[L_N32], g.cnt[L_N32], 32); });
+        TN.run("k_dict_num<u64>", g.cnt[L_N64], [&] { launch_dict_num(cn, L + g.off[L_N64], g.cnt[L_N64], 64); });
+        TN.run("k_copy_raw", g.cnt[L_RAW], [&] { launch_copy_raw(cn, L + g.off[L_RAW], g.cnt[L_RAW]); });
+        run_group_front_str(pl, T, c, g, 0);
         T.run("k_str_index", g.cnt[L_STR], [&] { launch_str_index(c, L + g.off[L_STR], g.cnt[L_STR]); });
         T.run("k_str_copy", g.cnt[L_STR], [&] { launch_str_copy(c, L + g.off[L_STR], g.cnt[L_STR]); });
+        if (fork) {  // the next group reuses this group's scratch: both streams must be done with it
+            HIP_TRY(hipEventRecord(pl->ev_join, pl->aux), return IXR_ERR_HIP);
+            HIP_TRY(hipStreamWaitEvent(st, pl->ev_join, 0), return IXR_ERR_HIP);
+        }
     }
     HIP_TRY(hipGetLastError(), return IXR_ERR_HIP);
     return 0;
@@ -410,7 +443,8 @@ extern "C" int32_t ixr_plan_run_dict_structs(ixr_plan* pl, const void* d_in, uin
     const int* L = pl->d_lists;
     run_parse_all(pl, T, c);
     for (const Group& g : pl->groups) {
-        run_group_front(pl, T, c, g, 1);
+        run_group_front_num(pl, T, c, g);
+        run_group_front_str(pl, T, c, g, 1);
         T.run("k_dict_struct", g.cnt[L_DICT], [&] { launch_dict_struct(c, L + g.off[L_DICT], g.cnt[L_DICT]); });
     }
     HIP_TRY(hipGetLastError(), return IXR_ERR_HIP);
