@@ -79,6 +79,11 @@ void    ixr_host_free_pinned(void* hptr);
 int32_t ixr_memcpy_h2d(int32_t device, void* dst_dev, const void* src_host, uint64_t bytes);
 int32_t ixr_memcpy_d2h(int32_t device, void* dst_host, const void* src_dev, uint64_t bytes);
 int32_t ixr_dev_synchronize(int32_t device);
+/* Streams for callers without a HIP binding of their own: a non-blocking hipStream_t as an opaque pointer, accepted by
+ * every `stream` parameter below.  No counterpart in the reference (its decode is synchronous on the calling thread). */
+void*   ixr_stream_create(int32_t device);
+void    ixr_stream_destroy(int32_t device, void* stream);
+int32_t ixr_stream_synchronize(int32_t device, void* stream);
 
 /* ---- batch decode, device resident (the hot path) -------------------------------------------------------------
  * A plan is built once per set of pack descriptors (DPN metadata is loaded when a segment is opened:

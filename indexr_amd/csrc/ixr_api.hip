@@ -99,6 +99,24 @@ extern "C" int32_t ixr_dev_synchronize(int32_t device) {
     return 0;
 }
 
+extern "C" void* ixr_stream_create(int32_t device) {
+    if (ixr_init(device) != 0) return nullptr;
+    hipStream_t st = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e != hipSuccess) { fail(IXR_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); return nullptr; }
+    return (void*)st;
+}
+extern "C" void ixr_stream_destroy(int32_t device, void* stream) {
+    if (!stream) return;
+    (void)hipSetDevice(device);
+    (void)hipStreamDestroy((hipStream_t)stream);
+}
+extern "C" int32_t ixr_stream_synchronize(int32_t device, void* stream) {
+    HIP_TRY(hipSetDevice(device), return IXR_ERR_HIP);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream), return IXR_ERR_HIP);
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------------------------------------------

@@ -57,6 +57,9 @@ _sig = {
     "ixr_memcpy_h2d": (_i32, [_i32, _vp, _vp, _u64]),
     "ixr_memcpy_d2h": (_i32, [_i32, _vp, _vp, _u64]),
     "ixr_dev_synchronize": (_i32, [_i32]),
+    "ixr_stream_create": (C.c_void_p, [_i32]),
+    "ixr_stream_destroy": (None, [_i32, C.c_void_p]),
+    "ixr_stream_synchronize": (_i32, [_i32, C.c_void_p]),
     "ixr_plan_create": (_vp, [_i32, C.POINTER(PackDesc), _i32, _u64]),
     "ixr_plan_destroy": (None, [_vp]),
     "ixr_plan_in_bytes": (_u64, [_vp]),

@@ -317,3 +317,35 @@ def test_coexists_with_torch_when_torch_is_imported_first():
             "import __graft_entry__ as g; g.smoke()")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_explicit_stream_repeated_runs_multiple_groups():
+    """The batch path on a caller-created stream: numeric and string packs in one plan (the two kinds of kernels run on two
+    internal streams that fork from and join the caller's), a scratch budget small enough for several groups, three
+    runs back to back into the same output arena; every run's checksums must match the host rows'."""
+    reqs = []
+    for pack_id in range(6):
+        for kind in (2, 4, 8, 10, 0, 9):
+            reqs.append((kind, pack_id, 65536 if pack_id < 5 else 777, 0))
+    descs, arena, out_bytes, sums = L.synth_build(reqs, 0xBEEF, threads=4)
+    plan = L.Plan(0, descs, 24 << 20)
+    stream = L.lib.ixr_stream_create(0)
+    assert stream
+    d_in = L.DeviceBuffer(0, len(arena))
+    d_out = L.DeviceBuffer(0, out_bytes + 16)
+    try:
+        d_in.upload(arena)
+        for rep in range(3):
+            d_out.upload(np.full(out_bytes + 16, 0x5A + rep, dtype=np.uint8))
+            plan.run(d_in.ptr, len(arena), d_out.ptr, out_bytes + 16, stream)
+            status, bad = plan.status(stream)
+            assert bad == 0 and all(int(s) == d.pack_size for s, d in zip(status, descs))
+            got = plan.checksums(d_out.ptr, out_bytes + 16, stream)
+            assert (got == sums).all(), "run %d" % rep
+        assert L.lib.ixr_stream_synchronize(0, stream) == 0
+    finally:
+        plan.destroy()
+        d_in.free()
+        d_out.free()
+        L.lib.ixr_stream_destroy(0, stream)
