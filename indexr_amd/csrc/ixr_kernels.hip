@@ -75,6 +75,9 @@ __device__ __forceinline__ uint32_t bit_width32(uint32_t v) { return v ? 32u - (
 // headers) from there.  One coalesced global load fills the window; every step of a serial walk then costs an LDS round
 // trip instead of a trip to L2/HBM.  All lanes of the wave call these functions with the same arguments.
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef IXR_FRONT_BATCH
+#define IXR_FRONT_BATCH 8
+#endif
 constexpr int kParseLaneThreshold = 16384;  // packs per launch from which k_parse_lanes is used
 constexpr uint32_t kWin = 4096;
 constexpr uint32_t kWinAlloc = kWin + 16;  // bytes of LDS per window (16 spare bytes so that 12-byte peeks never run off)
@@ -665,34 +668,39 @@ __global__ __launch_bounds__(256) void k_delta(const DevPack* __restrict__ packs
     const uint32_t* mb = (const uint32_t*)(min_delta + (P.obj_count + kBlock - 1) / kBlock);
     const uint32_t n = s.n;
     const int lane = tid & 63, wave = tid >> 6;
+    // consecutive values per thread (one mini-block header serves all of them): 8 pays for 32-bit values, 64-bit values
+    // are faster with 4 (three dword loads per extraction already)
+    constexpr int V = sizeof(U) == 4 ? 8 : 4;
+    constexpr uint32_t kChunk = 256 * V;  // values per workgroup iteration
     __shared__ U wsum[2][4];
     U carry = (U)s.first;
     int buf = 0;
-    // unpack the 4 values of this thread for the chunk starting at c0 (minDelta already added); zeros past the end
-    auto unpack4 = [&](uint32_t c0, U& d0, U& d1, U& d2, U& d3) {
-        const uint32_t i0 = c0 + 4 * tid;
-        d0 = d1 = d2 = d3 = 0;
+    // unpack the V values of this thread for the chunk starting at c0 (minDelta already added); zeros past the end
+    auto unpack = [&](uint32_t c0, U (&d)[V]) {
+        const uint32_t i0 = c0 + V * tid;
+#pragma unroll
+        for (int q = 0; q < V; q++) d[q] = 0;
         if (i0 < n) {
             const uint32_t hdr = mb[i0 >> 5];
             const uint32_t bw = hdr >> 24;
             const uint8_t* src = base + (hdr & 0xFFFFFFu);
             const U md = (U)min_delta[i0 >> 7];
             const uint32_t bit = (i0 & 31) * bw;
-            d0 = extract<U>(src, bit, bw) + md;
-            if (i0 + 1 < n) d1 = extract<U>(src, bit + bw, bw) + md;
-            if (i0 + 2 < n) d2 = extract<U>(src, bit + 2 * bw, bw) + md;
-            if (i0 + 3 < n) d3 = extract<U>(src, bit + 3 * bw, bw) + md;
+#pragma unroll
+            for (int q = 0; q < V; q++)
+                if (i0 + q < n) d[q] = extract<U>(src, bit + q * bw, bw) + md;
         }
     };
-    U d0, d1, d2, d3;
-    unpack4(0, d0, d1, d2, d3);
-    for (uint32_t c0 = 0; c0 < n; c0 += 1024, buf ^= 1) {
-        const uint32_t i0 = c0 + 4 * tid;
+    U d[V];
+    unpack(0, d);
+    for (uint32_t c0 = 0; c0 < n; c0 += kChunk, buf ^= 1) {
+        const uint32_t i0 = c0 + V * tid;
         // software pipeline: the next chunk's loads are issued before this chunk's scan and barrier
-        U e0, e1, e2, e3;
-        unpack4(c0 + 1024, e0, e1, e2, e3);
-        d1 += d0; d2 += d1; d3 += d2;
-        const U incl = wave_incl_scan<U>(d3);
+        U e[V];
+        unpack(c0 + kChunk, e);
+#pragma unroll
+        for (int q = 1; q < V; q++) d[q] += d[q - 1];
+        const U incl = wave_incl_scan<U>(d[V - 1]);
         if (lane == 63) wsum[buf][wave] = incl;
         __syncthreads();
         const U w0 = wsum[buf][0], w1 = wsum[buf][1], w2 = wsum[buf][2], w3 = wsum[buf][3];
@@ -700,22 +708,24 @@ __global__ __launch_bounds__(256) void k_delta(const DevPack* __restrict__ packs
         if (wave > 0) wprefix += w0;
         if (wave > 1) wprefix += w1;
         if (wave > 2) wprefix += w2;
-        const U pre = carry + wprefix + (incl - d3);
-        if (i0 + 3 < n) {
+        const U pre = carry + wprefix + (incl - d[V - 1]);
+        if (i0 + V - 1 < n) {
             if constexpr (sizeof(U) == 4) {
-                *(uint4*)(dst + i0) = make_uint4(d0 + pre, d1 + pre, d2 + pre, d3 + pre);
+#pragma unroll
+                for (int q = 0; q < V; q += 4) *(uint4*)(dst + i0 + q) = make_uint4(d[q] + pre, d[q + 1] + pre, d[q + 2] + pre, d[q + 3] + pre);
             } else {
                 ulonglong2* o2 = (ulonglong2*)(dst + i0);
-                o2[0] = make_ulonglong2(d0 + pre, d1 + pre);
-                o2[1] = make_ulonglong2(d2 + pre, d3 + pre);
+#pragma unroll
+                for (int q = 0; q < V; q += 2) o2[q / 2] = make_ulonglong2(d[q] + pre, d[q + 1] + pre);
             }
-        } else if (i0 < n) {
-            dst[i0] = d0 + pre;
-            if (i0 + 1 < n) dst[i0 + 1] = d1 + pre;
-            if (i0 + 2 < n) dst[i0 + 2] = d2 + pre;
+        } else {
+#pragma unroll
+            for (int q = 0; q < V; q++)
+                if (i0 + q < n) dst[i0 + q] = d[q] + pre;
         }
         carry += w0 + w1 + w2 + w3;
-        d0 = e0; d1 = e1; d2 = e2; d3 = e3;
+#pragma unroll
+        for (int q = 0; q < V; q++) d[q] = e[q];
     }
 }
 
@@ -1221,6 +1231,7 @@ __global__ __launch_bounds__(256) void k_front_decode(const DevPack* __restrict_
     FrontCtx f;
     if (!front_ctx(f, P, metas[pi], in, out, scratch, ro, use_ds, true)) return;
     const int lane = threadIdx.x & 63;
+    constexpr int kB = IXR_FRONT_BATCH;  // strings per step
     const uint32_t wave = __builtin_amdgcn_readfirstlane(bx * 4 + (threadIdx.x >> 6)), nwaves = gridDim.x * 4;
     for (uint32_t b = wave; b < f.nblk; b += nwaves) {
         const uint32_t i0 = b * kFrontBlock;
@@ -1235,12 +1246,12 @@ __global__ __launch_bounds__(256) void k_front_decode(const DevPack* __restrict_
             uint32_t cur = f.sum[(size_t)b * f.stride + j];
             // strings that end before our columns neither read nor write here: skip batches made of them only
             const uint64_t reach = __ballot(mlen > col0);
-            for (uint32_t k0 = 0; k0 < cnt; k0 += 8) {
-                if (((reach >> k0) & 0xFFu) == 0) continue;
-                // 8 strings per step: all suffix loads are issued before the first byte is consumed
-                uint32_t p[8], len[8], o[8], t[8];
+            for (uint32_t k0 = 0; k0 < cnt; k0 += kB) {
+                if (((reach >> k0) & ((1ull << kB) - 1ull)) == 0) continue;
+                // kB strings per step: all suffix loads are issued before the first byte is consumed
+                uint32_t p[kB], len[kB], o[kB], t[kB];
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
+                for (int q = 0; q < kB; q++) {
                     const uint32_t k = k0 + q;  // <= 63; lanes >= cnt hold length 0
                     p[q] = __builtin_amdgcn_readlane(mp, k);
                     len[q] = __builtin_amdgcn_readlane(mlen, k);
@@ -1249,8 +1260,13 @@ __global__ __launch_bounds__(256) void k_front_decode(const DevPack* __restrict_
                     // unconditional, clamped load (so + 0 is always readable: suffix bytes are followed by the id stream)
                     t[q] = f.sfx[(j >= p[q] && j < len[q]) ? sp + j : so];
                 }
+                // keep the loads together: without this the compiler sinks one of them into a conditional block behind a
+                // full wait, which costs a second memory round trip per batch
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
+                for (int q = 0; q < kB; q += 8)
+                    asm volatile("" : "+v"(t[q]), "+v"(t[q + 1]), "+v"(t[q + 2]), "+v"(t[q + 3]), "+v"(t[q + 4]), "+v"(t[q + 5]), "+v"(t[q + 6]), "+v"(t[q + 7]));
+#pragma unroll
+                for (int q = 0; q < kB; q++) {
                     cur = (j >= p[q] && j < len[q]) ? t[q] : cur;
                     if (j < len[q]) f.body[o[q] + j] = (uint8_t)cur;
                 }
