@@ -46,6 +46,7 @@ def parse_args():
     ap.add_argument("--scratch-gib", type=float, default=8.0)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU time of each cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--handback", action="store_true", help="also time the engine hand-back (decoded packs -> Spark column vector contents) on the first chunk, checked against the oracle")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the N > 1 code path on one GPU")
     ap.add_argument("--with-copies", action="store_true", help="also time H2D + decode + D2H from/to pinned host memory on a sample")
     return ap.parse_args()
@@ -195,6 +196,10 @@ def main():
     if args.with_copies and rank == 0:
         with_copies = time_with_copies(L, np, device, sample_for_cpu, args.scratch_gib)
 
+    handback = None
+    if args.handback and rank == 0:
+        handback = time_handback(L, np, device, sample_for_cpu, args.scratch_gib)
+
     # ------------------------------------------------------------------ CPU baseline (rank 0, bounded sample)
     cpu_baseline = None
     if rank == 0 and args.cpu_seconds > 0:
@@ -226,6 +231,8 @@ def main():
         }
         if with_copies:
             out["with_copies"] = with_copies
+        if handback:
+            out["handback"] = handback
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()
     plan.destroy()
@@ -326,6 +333,56 @@ def time_with_copies(L, np, device, sample, scratch_gib):
            "note": "synchronous H2D -> decode -> D2H from/to pinned host memory, no overlap"}
     plan.destroy(); d_in.free(); d_out.free()
     L.lib.ixr_host_free_pinned(h_in); L.lib.ixr_host_free_pinned(h_out)
+    return res
+
+
+def time_handback(L, np, device, sample, scratch_gib):
+    """Engine hand-back on the first chunk: decode, then decoded packs -> column vector contents for every row
+    (INT/FLOAT/DOUBLE as they are, LONG timestamps as DATETIME microseconds, strings as offset/length/bytes); the result of a
+    few packs is compared with the CPU oracle's restatement of DefaultPackReader."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    descs, arena = sample
+    plan = L.Plan(device, descs, int(scratch_gib * (1 << 30)))
+    in_bytes, out_bytes = len(arena), plan.out_bytes + 16
+    d_in, d_dec = L.DeviceBuffer(device, in_bytes), L.DeviceBuffer(device, out_bytes)
+    d_in.upload(arena)
+    plan.run(d_in.ptr, in_bytes, d_dec.ptr, out_bytes)
+    _, bad = plan.status()
+    sql_of = {1: L.SQL_INT, 2: L.SQL_DATETIME, 3: L.SQL_FLOAT, 4: L.SQL_DOUBLE, 5: L.SQL_VARCHAR}
+    hb, off = [], 0
+    for d in descs:
+        h = L.HandbackDesc(d.out_off, off, d.obj_count, d.data_size, sql_of[d.data_type], 0, d.obj_count, 0)
+        hb.append(h)
+        off += int(L.lib.ixr_handback_bound(h))
+    d_hb = L.DeviceBuffer(device, off + 16)
+    best = None
+    for it in range(4):
+        L.lib.ixr_dev_synchronize(device)
+        t = time.perf_counter()
+        status, nbad = L.handback_run(hb, d_dec.ptr, out_bytes, d_hb.ptr, off + 16, device)
+        dt = time.perf_counter() - t
+        if it and (best is None or dt < best):
+            best = dt
+    # parity on the first pack of every column
+    checked, seen = 0, set()
+    dec = None
+    for i, (d, h) in enumerate(zip(descs, hb)):
+        if d.data_type in seen:
+            continue
+        seen.add(d.data_type)
+        if dec is None:
+            dec = d_dec.download()
+            out = d_hb.download()
+        want, r = O.handback(h.sql_type, d.obj_count, dec[d.out_off:d.out_off + d.data_size], 0, d.obj_count)
+        if int(status[i]) != r or out[h.dst_off:h.dst_off + r].tobytes() != want.tobytes():
+            raise SystemExit("hand-back differs from the oracle on pack %d" % i)
+        checked += 1
+    produced = int(sum(int(s) for s in status))
+    res = {"GBps_in_plus_out": round((plan.total_out + produced) / best / 1e9, 1), "rows_per_s": round(plan.total_rows / best, 1),
+           "packs": plan.n, "bad": int(nbad) + int(bad), "checked_vs_oracle": checked, "ms": round(best * 1e3, 3),
+           "note": "wall time of ixr_handback_run incl. descriptor upload, status download and stream sync"}
+    plan.destroy(); d_in.free(); d_dec.free(); d_hb.free()
     return res
 
 

@@ -145,6 +145,37 @@ int32_t ixr_get_dict_struct(int32_t device, int32_t data_type, int32_t obj_count
 int32_t ixr_get_data_from_dict_struct(int32_t device, int32_t data_type, int32_t obj_count,
                                       const void* dict_struct, int32_t ds_size, void* out, int32_t out_limit);
 
+/* ---- engine hand-back on device -----------------------------------------------------------------------------------
+ * The step right after the decode in the Spark reader: decoded pack -> column vector contents for rows
+ * [row_offset, row_offset + row_count), DefaultPackReader.readByCopy / readBySet
+ * (indexr-spark/src/main/java/org/apache/spark/sql/execution/datasources/indexr/DefaultPackReader.java:164-241):
+ *   INT / BIGINT / FLOAT / DOUBLE   the rows as they are (HackColumnVector.copyInts ..., HackColumnVector.java:22-104)
+ *   DATE      int64 milliseconds -> int32 days, (int) (value / 86400000)          (:214-219)
+ *   DATETIME  int64 milliseconds -> int64 microseconds, value * 1000 (wrapping)   (:220-225)
+ *   VARCHAR   int32 arrayOffset[row_count] | int32 arrayLength[row_count] | the rows' bytes in row order, which is what
+ *             ColumnVector.putByteArray(rowId, bytes, off, len) leaves in its offset / length / child byte vectors (:226-232)
+ *   TIME      rejected like the reference does ("Unsupported date type", :233-234) -> IXR_ERR_UNSUPPORTED_TYPE
+ * Input: a decoded-pack arena as ixr_plan_run leaves it (src_off = the pack's out_off).  Output offsets must be multiples
+ * of IXR_ARENA_ALIGN; ixr_handback_bound gives the bytes a descriptor can produce.  status[i] receives the bytes written
+ * for descriptor i or a negative error.  The call synchronises with `stream`.  Returns the number of failed descriptors
+ * or a negative library error.
+ */
+enum { IXR_SQL_INT = 1, IXR_SQL_BIGINT = 2, IXR_SQL_FLOAT = 3, IXR_SQL_DOUBLE = 4, IXR_SQL_VARCHAR = 5, IXR_SQL_DATE = 6,
+       IXR_SQL_TIME = 7, IXR_SQL_DATETIME = 8 };
+typedef struct ixr_handback_desc {
+    uint64_t src_off;    /* decoded pack inside the decoded arena */
+    uint64_t dst_off;    /* output inside the hand-back arena, multiple of IXR_ARENA_ALIGN */
+    int32_t  obj_count;  /* rows in the pack */
+    int32_t  data_size;  /* dpn.dataSize of the pack */
+    int32_t  sql_type;   /* IXR_SQL_* */
+    int32_t  row_offset; /* first row handed back */
+    int32_t  row_count;  /* number of rows handed back */
+    int32_t  reserved;
+} ixr_handback_desc;
+uint64_t ixr_handback_bound(const ixr_handback_desc* desc);
+int32_t  ixr_handback_run(int32_t device, const ixr_handback_desc* descs, int32_t n, const void* d_decoded,
+                          uint64_t decoded_bytes, void* d_out, uint64_t out_bytes, int32_t* status, void* stream);
+
 /* ---- host-side write path (needed to build inputs; CPU only) --------------------------------------------------------
  * PackCompressor_VLT.compress (:23-128): codec choice and encoding of one pack. `data` is the decoded pack
  * (numbers: raw LE array; strings: StringsStruct, indexr-common/.../data/StringsStruct.java:12-17).

@@ -691,3 +691,57 @@ extern "C" int32_t ixr_get_data_from_dict_struct(int32_t device, int32_t data_ty
     memcpy(&total, (const uint8_t*)out + 4ull * (uint64_t)obj_count, 4);
     return 4 * (obj_count + 1) + total;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// engine hand-back (DefaultPackReader.java:164-241)
+// ---------------------------------------------------------------------------------------------------------------
+static_assert(sizeof(HandbackDesc) == sizeof(ixr_handback_desc), "device and ABI descriptor layouts must match");
+
+extern "C" uint64_t ixr_handback_bound(const ixr_handback_desc* d) {
+    if (!d || d->row_count < 0) return 0;
+    const uint64_t c = (uint64_t)d->row_count;
+    switch (d->sql_type) {
+        case IXR_SQL_INT: case IXR_SQL_FLOAT: case IXR_SQL_DATE: return align16(4 * c);
+        case IXR_SQL_BIGINT: case IXR_SQL_DOUBLE: case IXR_SQL_DATETIME: return align16(8 * c);
+        case IXR_SQL_VARCHAR: {
+            const uint64_t index = 4ull * ((uint64_t)d->obj_count + 1);
+            const uint64_t body = (uint64_t)d->data_size > index ? (uint64_t)d->data_size - index : 0;
+            return align16(8 * c + body);
+        }
+        default: return 16;
+    }
+}
+
+extern "C" int32_t ixr_handback_run(int32_t device, const ixr_handback_desc* descs, int32_t n, const void* d_decoded,
+                                    uint64_t decoded_bytes, void* d_out, uint64_t out_bytes, int32_t* status, void* stream) {
+    if (ixr_init(device) != 0) return IXR_ERR_NO_DEVICE;
+    if (!descs || n <= 0 || !d_decoded || !d_out || !status) return fail(IXR_ERR_INVALID_ARGUMENT, "null argument or no descriptors");
+    if (((uintptr_t)d_decoded & 15) || ((uintptr_t)d_out & 15)) return fail(IXR_ERR_INVALID_ARGUMENT, "arenas must be 16-byte aligned");
+    for (int i = 0; i < n; i++) {
+        const ixr_handback_desc& d = descs[i];
+        if (d.obj_count <= 0 || d.obj_count > IXR_PACK_MAX_ROWS || d.data_size < 0 || d.row_offset < 0 || d.row_count < 0 ||
+            (int64_t)d.row_offset + d.row_count > d.obj_count || (d.src_off % IXR_ARENA_ALIGN) || (d.dst_off % IXR_ARENA_ALIGN))
+            return fail(IXR_ERR_INVALID_ARGUMENT, "hand-back descriptor %d: bad row range, sizes or alignment", i);
+        if (d.src_off + (uint64_t)d.data_size > decoded_bytes) return fail(IXR_ERR_INVALID_ARGUMENT, "hand-back descriptor %d: pack outside the decoded arena", i);
+        if (d.dst_off + ixr_handback_bound(&d) > out_bytes) return fail(IXR_ERR_INVALID_ARGUMENT, "hand-back descriptor %d: output outside the arena", i);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    HandbackDesc* dd = nullptr;
+    int32_t* ds = nullptr;
+    int32_t rc = 0;
+    if (hipMalloc((void**)&dd, sizeof(HandbackDesc) * (size_t)n) != hipSuccess || hipMalloc((void**)&ds, sizeof(int32_t) * (size_t)n) != hipSuccess)
+        rc = fail(IXR_ERR_OUT_OF_MEMORY, "hipMalloc failed");
+    if (!rc && hipMemcpyAsync(dd, descs, sizeof(HandbackDesc) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess) rc = fail(IXR_ERR_HIP, "H2D failed");
+    if (!rc) {
+        launch_handback(st, dd, n, (const uint8_t*)d_decoded, (uint8_t*)d_out, ds);
+        if (hipGetLastError() != hipSuccess) rc = fail(IXR_ERR_HIP, "kernel launch failed");
+    }
+    if (!rc && hipMemcpyAsync(status, ds, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st) != hipSuccess) rc = fail(IXR_ERR_HIP, "D2H failed");
+    if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = fail(IXR_ERR_HIP, "stream synchronise failed");
+    if (dd) (void)hipFree(dd);
+    if (ds) (void)hipFree(ds);
+    if (rc) return rc;
+    int bad = 0;
+    for (int i = 0; i < n; i++) bad += status[i] < 0;
+    return bad;
+}

@@ -1652,6 +1652,72 @@ __global__ __launch_bounds__(256) void k_ds_rows(const DevPack* __restrict__ pac
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// k_handback: decoded pack -> Spark column vector contents (DefaultPackReader.readByCopy / readBySet,
+// DefaultPackReader.java:164-241).  grid = (blocks per descriptor, descriptors); elementwise, memory bound.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_handback(const HandbackDesc* __restrict__ descs, const uint8_t* __restrict__ decoded,
+                                                  uint8_t* __restrict__ out, int32_t* __restrict__ status) {
+    const HandbackDesc D = descs[blockIdx.y];
+    const uint8_t* src = decoded + D.src_off;
+    uint8_t* dst = out + D.dst_off;
+    const uint32_t n = (uint32_t)D.obj_count, r0 = (uint32_t)D.row_offset, cnt = (uint32_t)D.row_count;
+    const uint32_t tid = blockIdx.x * 256 + threadIdx.x, nthreads = gridDim.x * 256;
+    const bool reporter = tid == 0;
+    switch (D.sql_type) {
+        case 1: case 3:  // INT, FLOAT: the rows as they are
+            if ((uint64_t)n * 4 > (uint64_t)D.data_size) { if (reporter) status[blockIdx.y] = -1000; return; }
+            for (uint32_t i = tid; i < cnt; i += nthreads) ((uint32_t*)dst)[i] = ((const uint32_t*)src)[r0 + i];
+            if (reporter) status[blockIdx.y] = (int32_t)(cnt * 4);
+            return;
+        case 2: case 4:  // BIGINT, DOUBLE
+            if ((uint64_t)n * 8 > (uint64_t)D.data_size) { if (reporter) status[blockIdx.y] = -1000; return; }
+            for (uint32_t i = tid; i < cnt; i += nthreads) ((uint64_t*)dst)[i] = ((const uint64_t*)src)[r0 + i];
+            if (reporter) status[blockIdx.y] = (int32_t)(cnt * 8);
+            return;
+        case 6:  // DATE: (int) (ms / 86400000), truncating division, low 32 bits
+            if ((uint64_t)n * 8 > (uint64_t)D.data_size) { if (reporter) status[blockIdx.y] = -1000; return; }
+            for (uint32_t i = tid; i < cnt; i += nthreads) {
+                const int64_t v = ((const int64_t*)src)[r0 + i];
+                ((int32_t*)dst)[i] = (int32_t)(uint32_t)(uint64_t)(v / 86400000LL);
+            }
+            if (reporter) status[blockIdx.y] = (int32_t)(cnt * 4);
+            return;
+        case 8:  // DATETIME: ms * 1000, wrapping
+            if ((uint64_t)n * 8 > (uint64_t)D.data_size) { if (reporter) status[blockIdx.y] = -1000; return; }
+            for (uint32_t i = tid; i < cnt; i += nthreads) ((uint64_t*)dst)[i] = ((const uint64_t*)src)[r0 + i] * 1000ull;
+            if (reporter) status[blockIdx.y] = (int32_t)(cnt * 8);
+            return;
+        case 5: {  // VARCHAR: arrayOffset[cnt] | arrayLength[cnt] | bytes of the rows in order
+            if (4ull * (n + 1) > (uint64_t)D.data_size) { if (reporter) status[blockIdx.y] = -1000; return; }
+            const int32_t* off = (const int32_t*)src;
+            const int32_t a = off[r0], b = off[r0 + cnt];
+            if (a < 0 || b < a || 4ull * (n + 1) + (uint64_t)b > (uint64_t)D.data_size) { if (reporter) status[blockIdx.y] = -1000; return; }
+            int32_t* aoff = (int32_t*)dst;
+            int32_t* alen = aoff + cnt;
+            for (uint32_t i = tid; i < cnt; i += nthreads) {
+                const int32_t s = off[r0 + i], e = off[r0 + i + 1];
+                aoff[i] = s - a;
+                alen[i] = e - s;
+            }
+            // the rows' bytes are contiguous in the decoded body: one unaligned block copy, 16 bytes per lane
+            const uint8_t* sb = src + 4ull * (n + 1) + (uint32_t)a;
+            uint8_t* db = dst + 8ull * cnt;
+            const uint32_t len = (uint32_t)(b - a), whole = len & ~15u;
+            for (uint32_t i = tid * 16u; i < whole; i += nthreads * 16u) {
+                uint4 v;
+                __builtin_memcpy(&v, sb + i, 16);
+                __builtin_memcpy(db + i, &v, 16);
+            }
+            for (uint32_t i = whole + tid; i < len; i += nthreads) db[i] = sb[i];
+            if (reporter) status[blockIdx.y] = (int32_t)(8u * cnt + len);
+            return;
+        }
+        default:
+            if (reporter) status[blockIdx.y] = -102;  // "Unsupported date type" (DefaultPackReader.java:233-234)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // k_checksum: position-weighted checksum of every decoded pack (same formula as ixr_checksum on the host), so that
 // full-size outputs can be verified where they lie.
 // ---------------------------------------------------------------------------------------------------------------
@@ -1764,6 +1830,10 @@ void launch_ds_rows(const LaunchCtx& c, const int* list, int count, int mode) {
     if (mode == 0) hipLaunchKernelGGL(k_ds_rows<0>, g, b, 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
     else if (mode == 1) hipLaunchKernelGGL(k_ds_rows<1>, g, b, 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
     else hipLaunchKernelGGL(k_ds_rows<2>, g, b, 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+}
+void launch_handback(hipStream_t stream, const HandbackDesc* descs, int count, const uint8_t* decoded, uint8_t* out, int32_t* status) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_handback, dim3(16, count), dim3(256), 0, stream, descs, decoded, out, status);
 }
 void launch_checksum(const LaunchCtx& c, int count, unsigned long long* sums) {
     if (count <= 0) return;

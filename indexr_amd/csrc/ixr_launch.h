@@ -37,4 +37,11 @@ void launch_ds_rows(const LaunchCtx& c, const int* list, int count, int mode);  
 void launch_checksum(const LaunchCtx& c, int count, unsigned long long* sums);  // all packs of the plan
 void launch_dict_struct(const LaunchCtx& c, const int* list, int count);
 
+// engine hand-back (decoded pack -> column vector contents); descs / status are device arrays
+struct HandbackDesc {
+    uint64_t src_off, dst_off;
+    int32_t obj_count, data_size, sql_type, row_offset, row_count, reserved;
+};
+void launch_handback(hipStream_t stream, const HandbackDesc* descs, int count, const uint8_t* decoded, uint8_t* out, int32_t* status);
+
 }  // namespace ixr

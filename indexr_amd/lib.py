@@ -41,6 +41,15 @@ class PackDesc(C.Structure):
                 ("obj_count", C.c_int32), ("encode_type", C.c_int32), ("data_type", C.c_int32), ("reserved", C.c_int32)]
 
 
+class HandbackDesc(C.Structure):
+    """ixr_handback_desc: one decoded pack to turn into column vector contents (DefaultPackReader.java:164-241)"""
+    _fields_ = [("src_off", C.c_uint64), ("dst_off", C.c_uint64), ("obj_count", C.c_int32), ("data_size", C.c_int32),
+                ("sql_type", C.c_int32), ("row_offset", C.c_int32), ("row_count", C.c_int32), ("reserved", C.c_int32)]
+
+
+SQL_INT, SQL_BIGINT, SQL_FLOAT, SQL_DOUBLE, SQL_VARCHAR, SQL_DATE, SQL_TIME, SQL_DATETIME = range(1, 9)
+
+
 class SynthReq(C.Structure):
     _fields_ = [("kind", C.c_int32), ("pack_id", C.c_uint32), ("rows", C.c_int32), ("is_indexed", C.c_int32)]
 
@@ -77,6 +86,8 @@ _sig = {
     "ixr_get_data_from_dict_struct": (_i32, [_i32, _i32, _i32, _vp, _i32, _vp, _i32]),
     "ixr_compress_pack": (_i32, [_i32, _i32, _i32, _vp, _i32, _vp, _i32, C.POINTER(_i32)]),
     "ixr_compress_bound": (_i32, [_i32, _i32]),
+    "ixr_handback_bound": (_u64, [C.POINTER(HandbackDesc)]),
+    "ixr_handback_run": (_i32, [_i32, C.POINTER(HandbackDesc), _i32, _vp, _u64, _vp, _u64, C.POINTER(_i32), _vp]),
     "ixr_synth_data_type": (_i32, [_i32]),
     "ixr_synth_column": (_i32, [_i32, _u64, C.c_uint32, _i32, _vp, _i32]),
     "ixr_synth_build": (_i32, [C.POINTER(SynthReq), _i32, _u64, _i32, C.POINTER(PackDesc), C.POINTER(C.POINTER(C.c_uint8)),
@@ -271,3 +282,14 @@ def get_data_from_dict_struct(ds, data_type, obj_count, data_size, device=0):
     out = np.zeros(max(data_size, 1), dtype=np.uint8)
     r = lib.ixr_get_data_from_dict_struct(device, data_type, obj_count, _ptr(ds), len(ds), _ptr(out), data_size)
     return out[:data_size], r
+
+
+def handback_run(descs, d_decoded, decoded_bytes, d_out, out_bytes, device=0, stream=None):
+    """ixr_handback_run: -> (status per descriptor, number of failed descriptors)"""
+    n = len(descs)
+    arr = (HandbackDesc * n)(*descs)
+    st = (_i32 * n)()
+    bad = lib.ixr_handback_run(device, arr, n, d_decoded, decoded_bytes, d_out, out_bytes, st, stream)
+    if bad < 0:
+        raise IxrError(bad, "ixr_handback_run")
+    return np.frombuffer(st, dtype=np.int32).copy(), bad

@@ -1072,3 +1072,68 @@ int ixo_decode_batch(ixo_pack_desc* descs, int count, const uint8_t* in_arena, u
     for (int i = 0; i < count; i++) if (descs[i].status != descs[i].pack_size) bad++;
     return bad;
 }
+
+/* ---- engine hand-back (DefaultPackReader.java:164-241) ---- */
+int ixo_handback(int sql_type, int n, const uint8_t* decoded, int data_size, int row_offset, int row_count,
+                 uint8_t* out, int out_limit) {
+    if (n <= 0 || row_offset < 0 || row_count < 0 || row_offset + (long long)row_count > n) return -1000;
+    switch (sql_type) {
+        case 1: case 3: {  /* INT, FLOAT: readByCopy, HackColumnVector.copyInts/copyFloats */
+            if ((long long)n * 4 > data_size) return -1000;
+            if ((long long)row_count * 4 > out_limit) return IXO_BUFFER_OVERFLOW;
+            memcpy(out, decoded + (size_t)row_offset * 4, (size_t)row_count * 4);
+            return row_count * 4;
+        }
+        case 2: case 4: {  /* BIGINT, DOUBLE */
+            if ((long long)n * 8 > data_size) return -1000;
+            if ((long long)row_count * 8 > out_limit) return IXO_BUFFER_OVERFLOW;
+            memcpy(out, decoded + (size_t)row_offset * 8, (size_t)row_count * 8);
+            return row_count * 8;
+        }
+        case 6: {  /* DATE: stored as long milliseconds, Spark wants int days: (int) (value / MILLIS_PER_DAY)  :214-219 */
+            if ((long long)n * 8 > data_size) return -1000;
+            if ((long long)row_count * 4 > out_limit) return IXO_BUFFER_OVERFLOW;
+            for (int i = 0; i < row_count; i++) {
+                int64_t v;
+                memcpy(&v, decoded + (size_t)(row_offset + i) * 8, 8);
+                const int64_t q = v / 86400000LL;           /* Java long division truncates toward zero, like C */
+                const int32_t d = (int32_t)(uint32_t)(uint64_t)q;  /* (int) cast keeps the low 32 bits */
+                memcpy(out + (size_t)i * 4, &d, 4);
+            }
+            return row_count * 4;
+        }
+        case 8: {  /* DATETIME: milliseconds -> microseconds, value * 1000 with Java's wrapping multiply  :220-225 */
+            if ((long long)n * 8 > data_size) return -1000;
+            if ((long long)row_count * 8 > out_limit) return IXO_BUFFER_OVERFLOW;
+            for (int i = 0; i < row_count; i++) {
+                uint64_t v;
+                memcpy(&v, decoded + (size_t)(row_offset + i) * 8, 8);
+                v *= 1000u;
+                memcpy(out + (size_t)i * 8, &v, 8);
+            }
+            return row_count * 8;
+        }
+        case 5: {  /* VARCHAR: columnVector.putByteArray(id - offset, bytes, off, len) per row  :226-232 */
+            if (4LL * (n + 1) > data_size) return -1000;
+            int32_t a, b;
+            memcpy(&a, decoded + 4 * (size_t)row_offset, 4);
+            memcpy(&b, decoded + 4 * (size_t)(row_offset + row_count), 4);
+            if (a < 0 || b < a || 4LL * (n + 1) + b > data_size) return -1000;
+            if (8LL * row_count + (b - a) > out_limit) return IXO_BUFFER_OVERFLOW;
+            int32_t appended = 0;  /* arrayData().appendBytes returns the position the bytes went to */
+            for (int i = 0; i < row_count; i++) {
+                int32_t s, e;
+                memcpy(&s, decoded + 4 * (size_t)(row_offset + i), 4);
+                memcpy(&e, decoded + 4 * (size_t)(row_offset + i + 1), 4);
+                const int32_t len = e - s;
+                memcpy(out + 4 * (size_t)i, &appended, 4);
+                memcpy(out + 4 * (size_t)(row_count + i), &len, 4);
+                memcpy(out + 8 * (size_t)row_count + appended, decoded + 4 * (size_t)(n + 1) + s, (size_t)len);
+                appended += len;
+            }
+            return 8 * row_count + appended;
+        }
+        default:
+            return -102;  /* IllegalStateException("Unsupported date type ...")  :233-234 */
+    }
+}

@@ -79,6 +79,16 @@ typedef struct {
 } ixo_pack_desc;
 int ixo_decode_batch(ixo_pack_desc* descs, int count, const uint8_t* in_arena, uint8_t* out_arena, int threads);
 
+/* ---- engine hand-back: decoded pack -> Spark column vector contents ----
+ * Restates DefaultPackReader.readByCopy / readBySet (indexr-spark/.../indexr/DefaultPackReader.java:164-241) over
+ * DataPack.foreach (indexr-segment/.../pack/DataPack.java:257-458,627-706) for rows [row_offset, row_offset + row_count):
+ *   INT/BIGINT/FLOAT/DOUBLE  the rows as they are;  DATE  int32 (int)(ms / 86400000);  DATETIME  int64 ms * 1000;
+ *   VARCHAR  int32 arrayOffset[count] | int32 arrayLength[count] | bytes appended in row order (ColumnVector.putByteArray).
+ * sql_type: 1 INT 2 BIGINT 3 FLOAT 4 DOUBLE 5 VARCHAR 6 DATE 7 TIME 8 DATETIME.  Returns bytes written, -1 when out_limit is
+ * too small, -102 for a type the reader rejects (TIME: "Unsupported date type"), -1000 for bad arguments. */
+int ixo_handback(int sql_type, int n, const uint8_t* decoded, int data_size, int row_offset, int row_count,
+                 uint8_t* out, int out_limit);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,7 @@ for name, res, args in [
     ("ixo_compress_pack_as", C.c_int, [C.c_int, C.c_int, C.c_int, _u8p, C.c_int, _u8p, C.c_int]),
     ("ixo_decompress_pack", C.c_int, [C.c_int, C.c_int, C.c_int, _u8p, C.c_int, _u8p, C.c_int]),
     ("ixo_get_dict_struct", C.c_int, [C.c_int, C.c_int, _u8p, C.c_int, _u8p, C.c_int]),
+    ("ixo_handback", C.c_int, [C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]),
 ]:
     fn = getattr(lib, name)
     fn.restype = res
@@ -134,3 +135,13 @@ def data_from_dict_struct(ds, data_type, n, data_size):
     out = np.zeros(max(data_size, 1), dtype=np.uint8)
     r = lib.ixo_data_from_dict_struct(data_type, n, _p(ds), len(ds), _p(out), data_size)
     return out[:data_size], r
+
+
+def handback(sql_type, n, decoded, row_offset, row_count, out_limit=None):
+    """DefaultPackReader hand-back of rows [row_offset, row_offset+row_count) -> (bytes np.uint8, bytes-written-or-error)"""
+    decoded = np.ascontiguousarray(decoded, dtype=np.uint8)
+    if out_limit is None:
+        out_limit = len(decoded) + 8 * row_count + 16
+    out = np.zeros(max(out_limit, 1), dtype=np.uint8)
+    r = lib.ixo_handback(sql_type, n, _p(decoded), len(decoded), row_offset, row_count, _p(out), out_limit)
+    return out[:max(r, 0)], r
