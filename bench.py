@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU time of each cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--handback", action="store_true", help="also time the engine hand-back (decoded packs -> Spark column vector contents) on the first chunk, checked against the oracle")
+    ap.add_argument("--filter", action="store_true", help="also time predicate evaluation on dictionary ids (rows -> bitmap without decoding) on the first chunk, checked against the oracle")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the N > 1 code path on one GPU")
     ap.add_argument("--with-copies", action="store_true", help="also time H2D + decode + D2H from/to pinned host memory on a sample")
     return ap.parse_args()
@@ -200,6 +201,10 @@ def main():
     if args.handback and rank == 0:
         handback = time_handback(L, np, device, sample_for_cpu, args.scratch_gib)
 
+    filt = None
+    if args.filter and rank == 0:
+        filt = time_filter(L, np, device, sample_for_cpu, args.scratch_gib)
+
     # ------------------------------------------------------------------ CPU baseline (rank 0, bounded sample)
     cpu_baseline = None
     if rank == 0 and args.cpu_seconds > 0:
@@ -233,6 +238,8 @@ def main():
             out["with_copies"] = with_copies
         if handback:
             out["handback"] = handback
+        if filt:
+            out["filter"] = filt
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()
     plan.destroy()
@@ -334,6 +341,61 @@ def time_with_copies(L, np, device, sample, scratch_gib):
     plan.destroy(); d_in.free(); d_out.free()
     L.lib.ixr_host_free_pinned(h_in); L.lib.ixr_host_free_pinned(h_out)
     return res
+
+
+def time_filter(L, np, device, sample, scratch_gib):
+    """Predicate evaluation on dictionary ids on the first chunk: a range predicate (>= a key taken from the pack's own
+    rows) on every pack; bitmaps of a few packs are compared with the CPU oracle's restatement of ExtIndex_DictBits, which
+    is also timed on one thread."""
+    import struct
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    descs, arena = sample
+    plan = L.Plan(device, descs, int(scratch_gib * (1 << 30)))
+    in_bytes = len(arena)
+    d_in = L.DeviceBuffer(device, in_bytes)
+    d_in.upload(arena)
+    keys, is_str = [], []
+    for d in descs:  # one key per pack: a value that exists in the column's domain
+        if d.data_type == 5:
+            keys.append([b"www.m"]); is_str.append(True)
+        elif d.data_type in (3, 4):
+            keys.append([struct.unpack("<q", struct.pack("<d", 250.0))[0]]); is_str.append(False)
+        elif d.data_type == 2:
+            keys.append([1 << 40]); is_str.append(False)
+        else:
+            keys.append([500]); is_str.append(False)
+    values, offs = L.filter_keys(keys, is_str)
+    filters = [L.FilterDesc(L.FILTER_GREATER_EQUAL, 1, o) for o in offs]
+    d_bm = L.DeviceBuffer(device, L.BITMAP_BYTES * plan.n)
+    best = None
+    for it in range(4):
+        L.lib.ixr_dev_synchronize(device)
+        t = time.perf_counter()
+        res, nbad = L.plan_run_filter(plan, d_in.ptr, in_bytes, filters, values, d_bm.ptr, L.BITMAP_BYTES * plan.n)
+        dt = time.perf_counter() - t
+        if it and (best is None or dt < best):
+            best = dt
+    host = d_bm.download().view("<u8").reshape(plan.n, 1024)
+    checked, seen, cpu_s, cpu_rows = 0, {}, 0.0, 0
+    for i, d in enumerate(descs):
+        if seen.get(d.data_type, 0) >= 2:
+            continue
+        seen[d.data_type] = seen.get(d.data_type, 0) + 1
+        t = time.perf_counter()
+        want, bm = O.filter_pack(arena[d.in_off:d.in_off + d.pack_size], d.data_type, d.encode_type, d.obj_count, L.FILTER_GREATER_EQUAL, keys[i])
+        cpu_s += time.perf_counter() - t
+        cpu_rows += d.obj_count
+        if int(res[i]) != want or (want == L.BITMAP_SOME and not (host[i] == bm).all()):
+            raise SystemExit("filter differs from the oracle on pack %d" % i)
+        checked += 1
+    kinds = {int(k): int((res == k).sum()) for k in set(res.tolist())}
+    out = {"rows_per_s": round(plan.total_rows / best, 1), "packs": plan.n, "ms": round(best * 1e3, 3), "results": kinds,
+           "checked_vs_oracle": checked, "cpu_oracle_rows_per_s_1_thread": round(cpu_rows / cpu_s, 1),
+           "equivalent_decoded_GBps": round(plan.total_out / best / 1e9, 1),
+           "note": "wall time of ixr_plan_run_filter (parse + dictionaries + key search + row pass, incl. uploads, result download, sync); rows are never decoded"}
+    plan.destroy(); d_in.free(); d_bm.free()
+    return out
 
 
 def time_handback(L, np, device, sample, scratch_gib):

@@ -168,6 +168,8 @@ struct ixr_plan {
     size_t event_used = 0;
     std::vector<std::pair<std::string, KernelStat>> stats;
     int all_off = 0;  // offset of the identity list (all packs) in d_lists
+    std::vector<int> hlists;  // host copy of d_lists
+    int group_list_entry(const Group& g, int cls, int k) const { return hlists[(size_t)(g.off[cls] + k)]; }
     // The numeric and the string kernels of a group touch disjoint packs and disjoint scratch; they run on two streams
     // so that the latency-bound string kernels overlap the bandwidth-bound numeric ones.  `aux` forks off the caller's
     // stream at the start of every group and joins it at the end (events), so the caller still sees one ordered stream.
@@ -294,6 +296,7 @@ static ixr_plan* plan_create(int32_t device, const ixr_pack_desc* descs, int32_t
     pl->all_off = (int)lists.size();
     for (int i = 0; i < n_packs; i++) lists.push_back(i);
     hipError_t e;
+    pl->hlists = lists;
     if ((e = hipMalloc((void**)&pl->d_packs, sizeof(DevPack) * (size_t)n_packs)) != hipSuccess ||
         (e = hipMalloc((void**)&pl->d_metas, sizeof(PackMeta) * (size_t)n_packs)) != hipSuccess ||
         (e = hipMalloc((void**)&pl->d_lists, sizeof(int) * std::max<size_t>(lists.size(), 1))) != hipSuccess ||
@@ -743,5 +746,100 @@ extern "C" int32_t ixr_handback_run(int32_t device, const ixr_handback_desc* des
     if (rc) return rc;
     int bad = 0;
     for (int i = 0; i < n; i++) bad += status[i] < 0;
+    return bad;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// predicate evaluation on dictionary ids (ExtIndex_DictBits.java:33-180)
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int32_t ixr_plan_run_filter(ixr_plan* pl, const void* d_in, uint64_t in_bytes, const ixr_filter_desc* filters,
+                                       const void* values, uint64_t values_bytes, void* d_bitmaps, uint64_t bitmap_bytes,
+                                       int32_t* results, void* stream) {
+    if (!pl) return fail(IXR_ERR_INVALID_ARGUMENT, "null plan");
+    if (!d_in || !filters || !values || !d_bitmaps || !results) return fail(IXR_ERR_INVALID_ARGUMENT, "null argument");
+    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_bitmaps & 7)) return fail(IXR_ERR_INVALID_ARGUMENT, "misaligned device pointer");
+    if (in_bytes < pl->in_need) return fail(IXR_ERR_INVALID_ARGUMENT, "input arena too small");
+    if (bitmap_bytes < (uint64_t)pl->n * IXR_BITMAP_BYTES) return fail(IXR_ERR_INVALID_ARGUMENT, "bitmap area too small: %d packs need %llu bytes", pl->n, (unsigned long long)pl->n * IXR_BITMAP_BYTES);
+    // host-side checks of what the kernels will index with: key ranges inside the value buffer
+    std::vector<DevFilter> hf((size_t)pl->n);
+    uint64_t n_keys = 0;
+    for (int i = 0; i < pl->n; i++) {
+        const ixr_filter_desc& f = filters[i];
+        const bool str = pl->descs[(size_t)i].data_type == IXR_STRING;
+        if (f.op < IXR_FILTER_EQUAL || f.op > IXR_FILTER_BETWEEN || f.n_values < 1 || f.n_values > (1 << 20) || (f.values_off & 7) ||
+            (f.op == IXR_FILTER_BETWEEN && f.n_values < 2))
+            return fail(IXR_ERR_INVALID_ARGUMENT, "filter %d: bad op, value count or offset", i);
+        uint64_t need = str ? 4ull * ((uint64_t)f.n_values + 1) : 8ull * (uint64_t)f.n_values;
+        if (f.values_off + need > values_bytes) return fail(IXR_ERR_INVALID_ARGUMENT, "filter %d: keys outside the value buffer", i);
+        if (str) {
+            const int32_t* off = (const int32_t*)((const uint8_t*)values + f.values_off);
+            for (int v = 0; v < f.n_values; v++)
+                if (off[v] < 0 || off[v + 1] < off[v]) return fail(IXR_ERR_INVALID_ARGUMENT, "filter %d: key offsets not ascending", i);
+            need += (uint64_t)off[f.n_values];
+            if (f.values_off + need > values_bytes) return fail(IXR_ERR_INVALID_ARGUMENT, "filter %d: key bytes outside the value buffer", i);
+        }
+        DevFilter& d = hf[(size_t)i];
+        d.op = f.op; d.n_values = f.n_values; d.values_off = f.values_off; d.match_off = (uint32_t)n_keys;
+        d.result = IXR_ERR_BUG; d.from = d.to = d.n_match = d.pad = 0;
+        n_keys += (uint64_t)f.n_values;
+    }
+    HIP_TRY(hipSetDevice(pl->device), return IXR_ERR_HIP);
+    hipStream_t st = (hipStream_t)stream;
+    // The block-parallel front-coding decode keeps its per-block summaries in the pack's output region; there is no output
+    // arena here, so string dictionary packs get a slot of dataSize bytes in a temporary work area instead (reused group
+    // after group, like the scratch).
+    uint64_t work_bytes = 0;
+    for (const Group& g : pl->groups) {
+        uint64_t off = 0;
+        for (int k = 0; k < g.cnt[L_STR]; k++) {
+            const int i = pl->group_list_entry(g, L_STR, k);
+            pl->hpacks[(size_t)i].ds_off = off;
+            off += align16((uint64_t)pl->descs[(size_t)i].data_size);
+        }
+        work_bytes = std::max(work_bytes, off);
+    }
+    DevFilter* d_f = nullptr;
+    uint8_t* d_vals = nullptr;
+    uint32_t* d_match = nullptr;
+    uint8_t* d_work = nullptr;
+    int32_t rc = 0;
+    if (hipMalloc((void**)&d_f, sizeof(DevFilter) * (size_t)pl->n) != hipSuccess || hipMalloc((void**)&d_vals, values_bytes + 16) != hipSuccess ||
+        hipMalloc((void**)&d_match, 4 * n_keys + 16) != hipSuccess || hipMalloc((void**)&d_work, work_bytes + 16) != hipSuccess)
+        rc = fail(IXR_ERR_OUT_OF_MEMORY, "hipMalloc failed");
+    if (!rc && (hipMemcpyAsync(d_f, hf.data(), sizeof(DevFilter) * (size_t)pl->n, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipMemcpyAsync(d_vals, values, values_bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipMemcpyAsync(pl->d_packs, pl->hpacks.data(), sizeof(DevPack) * (size_t)pl->n, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess))  // hf / hpacks are pageable host memory
+        rc = fail(IXR_ERR_HIP, "H2D failed");
+    if (!rc) {
+        pl->timed.clear();
+        pl->event_used = 0;
+        Timer T{pl, st};
+        LaunchCtx c{st, pl->d_packs, pl->d_metas, (const uint8_t*)d_in, d_work, pl->d_scratch};
+        c.dict_only = 1;
+        const int* L = pl->d_lists;
+        run_parse_all(pl, T, c);
+        for (const Group& g : pl->groups) {
+            // dictionaries of the group into scratch, then keys -> ids, then rows -> bits.  Packs without a dictionary get
+            // their error code from the search kernel without being decoded.
+            run_group_front_num(pl, T, c, g);
+            run_group_front_str(pl, T, c, g, 1);
+            T.run("k_filter_search", g.cnt[L_ALL], [&] { launch_filter_search(c, L + g.off[L_ALL], g.cnt[L_ALL], d_f, d_vals, d_match); });
+            T.run("k_filter_rows", g.cnt[L_ALL], [&] { launch_filter_rows(c, L + g.off[L_ALL], g.cnt[L_ALL], d_f, d_match, (unsigned long long*)d_bitmaps); });
+        }
+        if (hipGetLastError() != hipSuccess) rc = fail(IXR_ERR_HIP, "kernel launch failed");
+    }
+    if (!rc && hipMemcpyAsync(hf.data(), d_f, sizeof(DevFilter) * (size_t)pl->n, hipMemcpyDeviceToHost, st) != hipSuccess) rc = fail(IXR_ERR_HIP, "D2H failed");
+    if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = fail(IXR_ERR_HIP, "stream synchronise failed");
+    if (d_f) (void)hipFree(d_f);
+    if (d_vals) (void)hipFree(d_vals);
+    if (d_match) (void)hipFree(d_match);
+    if (d_work) (void)hipFree(d_work);
+    if (rc) return rc;
+    int bad = 0;
+    for (int i = 0; i < pl->n; i++) {
+        results[i] = hf[(size_t)i].result;
+        bad += results[i] < 0;
+    }
     return bad;
 }

@@ -634,13 +634,14 @@ template <typename U> __device__ __forceinline__ U wave_incl_scan(U v) {
 template <typename U>
 __global__ __launch_bounds__(256) void k_delta(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                const PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
-                                               uint8_t* __restrict__ out, uint8_t* __restrict__ scratch) {
+                                               uint8_t* __restrict__ out, uint8_t* __restrict__ scratch, int dict_only) {
     const int pi = list[blockIdx.x];
     const int sk = blockIdx.y;
     const DevPack P = packs[pi];
     const PackMeta& M = metas[pi];
     if (M.status < 0) return;
     const int kind = M.kind;
+    if (dict_only && kind == K_DELTA_NUM) return;  // its rows would go to the output arena, which does not exist in this mode
     const uint8_t* base = in + P.in_off;
     const int tid = threadIdx.x;
 
@@ -983,10 +984,11 @@ __device__ __forceinline__ uint64_t str_dict_cap(const DevPack& P, const PackMet
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_str_dict_scan(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                        PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
-                                                       uint8_t* __restrict__ out, uint8_t* __restrict__ scratch) {
+                                                       uint8_t* __restrict__ out, uint8_t* __restrict__ scratch, int dict_only) {
     const int pi = list[blockIdx.x];
     PackMeta& M = metas[pi];
     if (M.status < 0 || (M.kind != K_DICT_STR && M.kind != K_DELTA_STR)) return;
+    if (dict_only && M.kind == K_DELTA_STR) return;  // a front-coded pack's "dictionary" is its output
     const DevPack P = packs[pi];
     const uint8_t* base = in + P.in_off;
     const uint32_t ec = M.entry_count;
@@ -1116,9 +1118,10 @@ __device__ __forceinline__ bool front_ctx(FrontCtx& f, const DevPack& P, const P
 
 __global__ __launch_bounds__(64) void k_front_serial(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                      const PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
-                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ scratch) {
+                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ scratch, int dict_only) {
     const int pi = list[blockIdx.y];
     const DevPack P = packs[pi];
+    if (dict_only && metas[pi].kind == K_DELTA_STR) return;
     FrontCtx f;
     if (!front_ctx(f, P, metas[pi], in, out, scratch, scratch, 0, false)) return;
     const uint32_t max_len = metas[pi].max_len;
@@ -1652,6 +1655,163 @@ __global__ __launch_bounds__(256) void k_ds_rows(const DevPack* __restrict__ pac
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Predicate evaluation on dictionary ids (ExtIndex_DictBits.java:33-180).
+//   k_filter_search  one wave per pack: looks the keys up in the decoded dictionary (BinarySearch.java: plain < and > on the
+//                    entry type, unsigned bytes then length for strings), one key per lane, and reduces them to what the
+//                    row pass needs: NONE / ALL, an id range [from, to), or a list of matched ids.
+//   k_filter_rows    one wave per 1024-row tile: expands the ids, tests them (range compare, or a bit mask over the
+//                    dictionary entries in LDS for id lists), ballots 64 rows into one bitmap word.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ int search_num(const T* e, int ec, T key) {
+    int from = 0, to = ec - 1;
+    while (from <= to) {
+        const int mid = (int)(((unsigned)from + (unsigned)to) >> 1);
+        const T v = e[mid];
+        if (v < key) from = mid + 1;
+        else if (v > key) to = mid - 1;
+        else return mid;
+    }
+    return -(from + 1);
+}
+__device__ __forceinline__ int search_str(const uint32_t* doff, const uint8_t* body, int ec, const uint8_t* key, int klen) {
+    int from = 0, to = ec - 1;
+    while (from <= to) {
+        const int mid = (int)(((unsigned)from + (unsigned)to) >> 1);
+        const uint32_t a = doff[mid], b = doff[mid + 1];
+        const int elen = (int)(b - a), len = min(elen, klen);
+        int c = 0;
+        for (int i = 0; i < len && c == 0; i++) c = (int)body[a + i] - (int)key[i];  // BytesUtil.compareBytes :7-19
+        if (c == 0) c = elen - klen;
+        if (c < 0) from = mid + 1;
+        else if (c > 0) to = mid - 1;
+        else return mid;
+    }
+    return -(from + 1);
+}
+
+__global__ __launch_bounds__(64) void k_filter_search(const DevPack* __restrict__ packs, const int* __restrict__ list,
+                                                      const PackMeta* __restrict__ metas, const uint8_t* __restrict__ scratch,
+                                                      DevFilter* __restrict__ filters, const uint8_t* __restrict__ values,
+                                                      uint32_t* __restrict__ matches) {
+    const int pi = list[blockIdx.x], lane = threadIdx.x;
+    const DevPack& P = packs[pi];
+    const PackMeta& M = metas[pi];
+    DevFilter& F = filters[pi];
+    if (M.status < 0) { if (lane == 0) F.result = M.status; return; }
+    if (P.encode_type != 6 || (M.kind != K_DICT_NUM && M.kind != K_DICT_STR)) { if (lane == 0) F.result = -3; return; }
+    const int ec = (int)M.entry_count, nv = F.n_values, op = F.op;
+    const uint8_t* dict = scratch + P.s_dict;
+    const uint8_t* vals = values + F.values_off;
+    auto lookup = [&](int v) -> int {  // searchEntry :33-58
+        if (P.width == 0) {
+            const int32_t* koff = (const int32_t*)vals;
+            const uint8_t* kbody = vals + 4ull * ((uint32_t)nv + 1);
+            return search_str((const uint32_t*)dict, dict + 4ull * ((uint32_t)ec + 1), ec, kbody + koff[v], koff[v + 1] - koff[v]);
+        }
+        const int64_t num = ((const int64_t*)vals)[v];
+        switch (P.data_type) {
+            case 1: return search_num<int32_t>((const int32_t*)dict, ec, (int32_t)(uint32_t)(uint64_t)num);
+            case 2: return search_num<int64_t>((const int64_t*)dict, ec, num);
+            case 3: return search_num<float>((const float*)dict, ec, (float)__longlong_as_double(num));
+            default: return search_num<double>((const double*)dict, ec, __longlong_as_double(num));
+        }
+    };
+    if (op == 1 || op == 2) {  // equal :60-79, in :81-113
+        uint32_t total = 0;
+        for (int v0 = 0; v0 < nv; v0 += 64) {
+            const int v = v0 + lane;
+            const int id = v < nv ? lookup(v) : -1;
+            const uint64_t hit = __ballot(id >= 0);
+            if (id >= 0) matches[F.match_off + total + __popcll(hit & ((1ull << lane) - 1ull))] = (uint32_t)id;
+            total += (uint32_t)__popcll(hit);
+        }
+        if (lane == 0) {
+            F.n_match = total;
+            F.result = total == 0 ? 0 : ((op == 1 && ec == 1) ? 1 : 2);
+        }
+    } else if (op == 3 || op == 4) {  // greater :115-145
+        if (lane == 0) {
+            const int id = lookup(0);
+            const int start = id >= 0 ? (op == 4 ? id : id + 1) : -id - 1;
+            F.from = (uint32_t)start; F.to = (uint32_t)ec; F.n_match = 0;
+            F.result = start >= ec ? 0 : (start == 0 ? 1 : 2);
+        }
+    } else if (op == 5 && nv >= 2) {  // between :147-180
+        const int id = lane < 2 ? lookup(lane) : 0;
+        const int id1 = __shfl(id, 0), id2 = __shfl(id, 1);
+        if (lane == 0) {
+            const int from = id1 >= 0 ? id1 : -id1 - 1, to = id2 >= 0 ? id2 + 1 : -id2 - 1;
+            F.from = (uint32_t)max(from, 0); F.to = (uint32_t)max(to, 0); F.n_match = 0;
+            if (!(from >= 0 && from < ec) || !(to >= 0 && to <= ec)) F.result = -100;  // Preconditions.checkState :165-166
+            else F.result = to - from <= 0 ? 0 : (to - from >= ec ? 1 : 2);
+        }
+    } else if (lane == 0) {
+        F.result = -1000;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_filter_rows(const DevPack* __restrict__ packs, const int* __restrict__ list,
+                                                     const PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
+                                                     DevFilter* __restrict__ filters,
+                                                     const uint32_t* __restrict__ matches, unsigned long long* __restrict__ bitmaps,
+                                                     const uint8_t* __restrict__ scratch) {
+    __shared__ uint16_t s_ids[4][kRleTile];
+    __shared__ __align__(16) uint8_t s_win[4][kWinAlloc];
+    __shared__ uint32_t s_emask[65536 / 32];  // one bit per dictionary entry: is it one of the matched ids?
+    const int pi = list[blockIdx.y], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const DevPack& P = packs[pi];
+    const PackMeta& M = metas[pi];
+    const DevFilter F = filters[pi];
+    const uint32_t n = (uint32_t)P.obj_count;
+    const uint32_t tile = blockIdx.x * 4 + wave, tile_start = tile * kRleTile;
+    unsigned long long* words = bitmaps + (size_t)pi * 1024 + tile * 16;
+    const bool by_set = F.result == 2 && (F.op == 1 || F.op == 2);
+    if (by_set) {  // workgroup-uniform
+        const uint32_t ew = (M.entry_count + 31) / 32;
+        for (uint32_t i = threadIdx.x; i < ew; i += 256) s_emask[i] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < F.n_match; i += 256) {
+            const uint32_t id = matches[F.match_off + i];
+            atomicOr(&s_emask[id >> 5], 1u << (id & 31));
+        }
+        __syncthreads();
+    }
+    if (F.result != 2 || tile_start >= n) {
+        // NONE, errors and rows past the pack: zeros; ALL: ones for the rows that exist
+        if (lane < 16) {
+            unsigned long long w = 0;
+            if (F.result == 1 && tile_start < n) {
+                const uint32_t r = tile_start + lane * 64;
+                w = r + 64 <= n ? ~0ull : (r < n ? ((1ull << (n - r)) - 1ull) : 0ull);
+            }
+            words[lane] = w;
+        }
+        return;
+    }
+    const uint32_t tile_end = min(n, tile_start + (uint32_t)kRleTile), cnt = tile_end - tile_start;
+    uint16_t* ids = s_ids[wave];
+    const uint4 seg = ((const uint4*)(scratch + P.s_restart))[tile];
+    Win w;
+    w.init(in + P.in_off, (uint32_t)P.pack_size, s_win[wave]);
+    rle_tile_expand(w, M.id_bw, M.ids_off + 4 + M.ids_len, seg, tile_start, tile_end, ids);
+    bool bad = false;
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const uint32_t r = q * 64 + lane;
+        const uint32_t id = r < cnt ? ids[r] : 0u;
+        if (id >= M.entry_count) bad = true;
+        bool hit;
+        if (by_set) hit = id < M.entry_count && ((s_emask[id >> 5] >> (id & 31)) & 1u);
+        else hit = id >= F.from && id < F.to;
+        const unsigned long long word = __ballot(hit && r < cnt);
+        if (lane == q) mine = word;
+    }
+    if (lane < 16) words[lane] = mine;
+    if (bad) filters[pi].result = E_CORRUPT;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // k_handback: decoded pack -> Spark column vector contents (DefaultPackReader.readByCopy / readBySet,
 // DefaultPackReader.java:164-241).  grid = (blocks per descriptor, descriptors); elementwise, memory bound.
 // ---------------------------------------------------------------------------------------------------------------
@@ -1766,10 +1926,10 @@ void launch_delta(const LaunchCtx& c, const int* list, int count, int width, int
     if (count <= 0) return;
     if (width == 64)
         hipLaunchKernelGGL(k_delta<uint64_t>, dim3(count, streams), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out,
-                           c.scratch);
+                           c.scratch, c.dict_only);
     else
         hipLaunchKernelGGL(k_delta<uint32_t>, dim3(count, streams), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out,
-                           c.scratch);
+                           c.scratch, c.dict_only);
 }
 void launch_dict_num(const LaunchCtx& c, const int* list, int count, int width) {
     if (count <= 0) return;
@@ -1787,11 +1947,13 @@ void launch_copy_raw(const LaunchCtx& c, const int* list, int count) {
 }
 void launch_str_dict_scan(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_str_dict_scan, dim3(count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+    hipLaunchKernelGGL(k_str_dict_scan, dim3(count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch,
+                       c.dict_only);
 }
 void launch_front_serial(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_front_serial, dim3(4, count), dim3(64), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+    hipLaunchKernelGGL(k_front_serial, dim3(4, count), dim3(64), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch,
+                       c.dict_only);
 }
 void launch_front_summary(const LaunchCtx& c, const int* list, int count, int use_ds) {
     if (count <= 0) return;
@@ -1830,6 +1992,16 @@ void launch_ds_rows(const LaunchCtx& c, const int* list, int count, int mode) {
     if (mode == 0) hipLaunchKernelGGL(k_ds_rows<0>, g, b, 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
     else if (mode == 1) hipLaunchKernelGGL(k_ds_rows<1>, g, b, 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
     else hipLaunchKernelGGL(k_ds_rows<2>, g, b, 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+}
+void launch_filter_search(const LaunchCtx& c, const int* list, int count, DevFilter* filters, const uint8_t* values, uint32_t* matches) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_filter_search, dim3(count), dim3(64), 0, c.stream, c.packs, list, c.metas, c.scratch, filters, values, matches);
+}
+void launch_filter_rows(const LaunchCtx& c, const int* list, int count, DevFilter* filters, const uint32_t* matches,
+                        unsigned long long* bitmaps) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_filter_rows, dim3(IXR_PACK_TILES / 4, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, filters,
+                       matches, bitmaps, c.scratch);
 }
 void launch_handback(hipStream_t stream, const HandbackDesc* descs, int count, const uint8_t* decoded, uint8_t* out, int32_t* status) {
     if (count <= 0) return;

@@ -17,6 +17,7 @@ struct LaunchCtx {
     const uint8_t* in;     // input arena
     uint8_t* out;          // output arena
     uint8_t* scratch;      // scratch base of the current group
+    int dict_only = 0;     // 1: build dictionaries only; packs whose decode writes straight to the output arena are skipped
 };
 
 // `list` is a device array of `count` pack indices.
@@ -36,6 +37,20 @@ void launch_ds_meta(const LaunchCtx& c, const int* list, int count);
 void launch_ds_rows(const LaunchCtx& c, const int* list, int count, int mode);  // 0: 32 bit, 1: 64 bit, 2: strings
 void launch_checksum(const LaunchCtx& c, int count, unsigned long long* sums);  // all packs of the plan
 void launch_dict_struct(const LaunchCtx& c, const int* list, int count);
+
+// predicate evaluation on dictionary ids: one record per pack of the plan, in device memory
+struct DevFilter {
+    int32_t op, n_values;
+    uint64_t values_off;  // into the device copy of the key buffer
+    uint32_t match_off;   // into the matched-id array (one slot per key)
+    int32_t result;       // out: 0 none, 1 all, 2 bitmap, < 0 error
+    uint32_t from, to;    // out: id range [from, to) for the range predicates
+    uint32_t n_match;     // out: number of matched ids (EQUAL, IN)
+    uint32_t pad;
+};
+void launch_filter_search(const LaunchCtx& c, const int* list, int count, DevFilter* filters, const uint8_t* values, uint32_t* matches);
+void launch_filter_rows(const LaunchCtx& c, const int* list, int count, DevFilter* filters, const uint32_t* matches,
+                        unsigned long long* bitmaps);
 
 // engine hand-back (decoded pack -> column vector contents); descs / status are device arrays
 struct HandbackDesc {

@@ -50,6 +50,16 @@ class HandbackDesc(C.Structure):
 SQL_INT, SQL_BIGINT, SQL_FLOAT, SQL_DOUBLE, SQL_VARCHAR, SQL_DATE, SQL_TIME, SQL_DATETIME = range(1, 9)
 
 
+class FilterDesc(C.Structure):
+    """ixr_filter_desc: a predicate on one pack's dictionary ids (ExtIndex_DictBits.java)"""
+    _fields_ = [("op", C.c_int32), ("n_values", C.c_int32), ("values_off", C.c_uint64)]
+
+
+FILTER_EQUAL, FILTER_IN, FILTER_GREATER, FILTER_GREATER_EQUAL, FILTER_BETWEEN = 1, 2, 3, 4, 5
+BITMAP_NONE, BITMAP_ALL, BITMAP_SOME = 0, 1, 2
+BITMAP_BYTES = 8192
+
+
 class SynthReq(C.Structure):
     _fields_ = [("kind", C.c_int32), ("pack_id", C.c_uint32), ("rows", C.c_int32), ("is_indexed", C.c_int32)]
 
@@ -86,6 +96,7 @@ _sig = {
     "ixr_get_data_from_dict_struct": (_i32, [_i32, _i32, _i32, _vp, _i32, _vp, _i32]),
     "ixr_compress_pack": (_i32, [_i32, _i32, _i32, _vp, _i32, _vp, _i32, C.POINTER(_i32)]),
     "ixr_compress_bound": (_i32, [_i32, _i32]),
+    "ixr_plan_run_filter": (_i32, [_vp, _vp, _u64, C.POINTER(FilterDesc), _vp, _u64, _vp, _u64, C.POINTER(_i32), _vp]),
     "ixr_handback_bound": (_u64, [C.POINTER(HandbackDesc)]),
     "ixr_handback_run": (_i32, [_i32, C.POINTER(HandbackDesc), _i32, _vp, _u64, _vp, _u64, C.POINTER(_i32), _vp]),
     "ixr_synth_data_type": (_i32, [_i32]),
@@ -293,3 +304,32 @@ def handback_run(descs, d_decoded, decoded_bytes, d_out, out_bytes, device=0, st
     if bad < 0:
         raise IxrError(bad, "ixr_handback_run")
     return np.frombuffer(st, dtype=np.int32).copy(), bad
+
+
+def filter_keys(keys_per_pack, is_string_per_pack):
+    """Packs the keys of every pack's predicate into one value buffer -> (np.uint8 buffer, values_off per pack).
+    Numeric keys are the reference's long numValue (ints as they are, float / double keys as the raw bits of the double)."""
+    parts, offs, pos = [], [], 0
+    for keys, is_str in zip(keys_per_pack, is_string_per_pack):
+        offs.append(pos)
+        if is_str:
+            o = np.zeros(len(keys) + 1, dtype="<i4")
+            o[1:] = np.cumsum([len(k) for k in keys])
+            b = o.tobytes() + b"".join(keys)
+        else:
+            b = np.asarray(keys, dtype="<i8").tobytes()
+        b += b"\0" * (-len(b) % 8)
+        parts.append(b)
+        pos += len(b)
+    return np.frombuffer(b"".join(parts) + b"\0" * 8, dtype=np.uint8).copy(), offs
+
+
+def plan_run_filter(plan, d_in, in_bytes, filters, values, d_bitmaps, bitmap_bytes, stream=None):
+    """ixr_plan_run_filter: -> (results per pack, number of packs with a negative result)"""
+    arr = (FilterDesc * plan.n)(*filters)
+    res = (_i32 * plan.n)()
+    values = np.ascontiguousarray(values, dtype=np.uint8)
+    bad = lib.ixr_plan_run_filter(plan.handle, d_in, in_bytes, arr, _ptr(values), len(values), d_bitmaps, bitmap_bytes, res, stream)
+    if bad < 0:
+        raise IxrError(bad, "ixr_plan_run_filter")
+    return np.frombuffer(res, dtype=np.int32).copy(), bad

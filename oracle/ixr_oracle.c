@@ -1137,3 +1137,97 @@ int ixo_handback(int sql_type, int n, const uint8_t* decoded, int data_size, int
             return -102;  /* IllegalStateException("Unsupported date type ...")  :233-234 */
     }
 }
+
+/* ---- predicate evaluation on dictionary ids (ExtIndex_DictBits.java) ---- */
+/* searchEntry (:33-58) with BinarySearch.binarySearch{Ints,Longs,Floats,Doubles,Strings} (BinarySearch.java:27-47,
+ * 100-120,162-181,229-248,295-316): plain < and > on the entry type; -(insertion point) - 1 when absent. */
+static int search_entry(int data_type, const uint8_t* entries, int ec, int64_t num, const uint8_t* key, int key_len) {
+    int from = 0, to = ec - 1;
+    const uint8_t* body = entries + 4 * ((size_t)ec + 1);
+    double dkey; memcpy(&dkey, &num, 8);
+    const float fkey = (float)dkey;      /* (float) Double.longBitsToDouble(numValue) */
+    const int32_t ikey = (int32_t)(uint32_t)(uint64_t)num; /* (int) numValue */
+    while (from <= to) {
+        const int mid = (int)(((unsigned)from + (unsigned)to) >> 1);
+        int lt, gt;
+        switch (data_type) {
+            case IXO_INT: { int32_t v = ld32(entries + ((size_t)mid << 2)); lt = v < ikey; gt = v > ikey; break; }
+            case IXO_LONG: { int64_t v = ld64(entries + ((size_t)mid << 3)); lt = v < num; gt = v > num; break; }
+            case IXO_FLOAT: { float v; memcpy(&v, entries + ((size_t)mid << 2), 4); lt = v < fkey; gt = v > fkey; break; }
+            case IXO_DOUBLE: { double v; memcpy(&v, entries + ((size_t)mid << 3), 8); lt = v < dkey; gt = v > dkey; break; }
+            default: {
+                const int32_t a = ld32(entries + 4 * (size_t)mid), b = ld32(entries + 4 * (size_t)(mid + 1));
+                const int c = compare_bytes(body + a, b - a, key, key_len);
+                lt = c < 0; gt = c > 0;
+            }
+        }
+        if (lt) from = mid + 1; else if (gt) to = mid - 1; else return mid;
+    }
+    return -(from + 1);
+}
+
+int ixo_filter(int data_type, int encode_type, int n, const uint8_t* pack, int pack_size, int op, int n_values,
+               const int64_t* num_values, const uint8_t* str_values, uint64_t* bitmap) {
+    if (encode_type != IXO_DICT_COMPRESS) return IXO_DATA_IMPROPER;  /* only dict-encoded packs get ExtIndex_DictBits */
+    if (pack_size < 4 || n_values < 1) return -1000;
+    const int ds_size = ld32(pack);
+    if (ds_size < 8) return IXO_DATA_CORRUPTED;
+    uint8_t* ds = (uint8_t*)calloc((size_t)ds_size + 16, 1);
+    const int consumed = ixo_get_dict_struct(data_type, n, pack, pack_size, ds, ds_size);
+    if (consumed < 0) { free(ds); return consumed; }
+    const int ec = ld32(ds);
+    const uint8_t* entries = ds + 4;
+    const int dict_size = ixo_dict_struct_size(data_type, ds) - 4 - 4 - 4 * n;
+    const uint8_t* ids = ds + 4 + dict_size + 4;
+    memset(bitmap, 0, 8192);
+    int result = 2;
+#define KEY(i, kp, kl) do { if (data_type == IXO_STRING) { int32_t a_ = ld32(str_values + 4 * (size_t)(i)), b_ = ld32(str_values + 4 * (size_t)((i) + 1)); \
+        kp = str_values + 4 * ((size_t)n_values + 1) + a_; kl = b_ - a_; } else { kp = NULL; kl = 0; } } while (0)
+#define NUM(i) (data_type == IXO_STRING ? 0 : num_values[i])
+    const uint8_t* kp; int kl;
+    if (op == 1) {  /* equal */
+        KEY(0, kp, kl);
+        const int id = search_entry(data_type, entries, ec, NUM(0), kp, kl);
+        if (id < 0) result = 0;
+        else if (ec == 1) result = 1;
+        else for (int i = 0; i < n; i++) if (ld32(ids + ((size_t)i << 2)) == id) bitmap[i >> 6] |= 1ull << (i & 63);
+    } else if (op == 2) {  /* in */
+        int* found = (int*)malloc(sizeof(int) * (size_t)n_values);
+        int m = 0;
+        for (int v = 0; v < n_values; v++) {
+            KEY(v, kp, kl);
+            const int id = search_entry(data_type, entries, ec, NUM(v), kp, kl);
+            if (id >= 0) found[m++] = id;
+        }
+        if (m == 0) result = 0;
+        else for (int i = 0; i < n; i++) {
+            const int vid = ld32(ids + ((size_t)i << 2));
+            for (int e = 0; e < m; e++) if (vid == found[e]) bitmap[i >> 6] |= 1ull << (i & 63);
+        }
+        free(found);
+    } else if (op == 3 || op == 4) {  /* greater, acceptEqual = (op == 4) */
+        KEY(0, kp, kl);
+        const int id = search_entry(data_type, entries, ec, NUM(0), kp, kl);
+        const int start = id >= 0 ? (op == 4 ? id : id + 1) : -id - 1;
+        if (start >= ec) result = 0;
+        else if (start == 0) result = 1;
+        else for (int i = 0; i < n; i++) if (ld32(ids + ((size_t)i << 2)) >= start) bitmap[i >> 6] |= 1ull << (i & 63);
+    } else if (op == 5) {  /* between */
+        if (n_values < 2) { free(ds); return -1000; }
+        KEY(0, kp, kl);
+        const int id1 = search_entry(data_type, entries, ec, NUM(0), kp, kl);
+        KEY(1, kp, kl);
+        const int id2 = search_entry(data_type, entries, ec, NUM(1), kp, kl);
+        const int from = id1 >= 0 ? id1 : -id1 - 1, to = id2 >= 0 ? id2 + 1 : -id2 - 1;
+        if (!(from >= 0 && from < ec) || !(to >= 0 && to <= ec)) result = IXO_BUG;  /* Preconditions.checkState :165-166 */
+        else if (to - from <= 0) result = 0;
+        else if (to - from >= ec) result = 1;
+        else for (int i = 0; i < n; i++) { const int id = ld32(ids + ((size_t)i << 2)); if (id >= from && id < to) bitmap[i >> 6] |= 1ull << (i & 63); }
+    } else {
+        result = -1000;
+    }
+#undef KEY
+#undef NUM
+    free(ds);
+    return result;
+}

@@ -89,6 +89,16 @@ int ixo_decode_batch(ixo_pack_desc* descs, int count, const uint8_t* in_arena, u
 int ixo_handback(int sql_type, int n, const uint8_t* decoded, int data_size, int row_offset, int row_count,
                  uint8_t* out, int out_limit);
 
+/* ---- predicate evaluation on dictionary ids ----
+ * Restates ExtIndex_DictBits (indexr-vlt-segment/.../vlt/segment/index/ExtIndex_DictBits.java:33-180) over the pack's
+ * DictStruct: op 1 equal (:60-79), 2 in (:81-113), 3 greater (:115-145, acceptEqual = false), 4 greater with acceptEqual,
+ * 5 between (:147-180).  num_values: the reference's long numValue per key (INT/LONG: the value; FLOAT/DOUBLE: raw long bits
+ * of the key as a double, :44,47); str_values: a StringsStruct of the keys.  bitmap: 1024 little-endian 64-bit words
+ * (BitMap / DirectBitMap: row i is bit i & 63 of word i >> 6).  Returns 0 NONE, 1 ALL, 2 a bitmap; -100 where the reference's
+ * Preconditions.checkState fails (:165-166); -3 when the pack is not DICT_COMPRESS; other negatives: decode errors. */
+int ixo_filter(int data_type, int encode_type, int n, const uint8_t* pack, int pack_size, int op, int n_values,
+               const int64_t* num_values, const uint8_t* str_values, uint64_t* bitmap);
+
 #ifdef __cplusplus
 }
 #endif

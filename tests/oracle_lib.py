@@ -57,6 +57,7 @@ for name, res, args in [
     ("ixo_compress_pack_as", C.c_int, [C.c_int, C.c_int, C.c_int, _u8p, C.c_int, _u8p, C.c_int]),
     ("ixo_decompress_pack", C.c_int, [C.c_int, C.c_int, C.c_int, _u8p, C.c_int, _u8p, C.c_int]),
     ("ixo_get_dict_struct", C.c_int, [C.c_int, C.c_int, _u8p, C.c_int, _u8p, C.c_int]),
+    ("ixo_filter", C.c_int, [C.c_int, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), _u8p, C.POINTER(C.c_uint64)]),
     ("ixo_handback", C.c_int, [C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]),
 ]:
     fn = getattr(lib, name)
@@ -145,3 +146,18 @@ def handback(sql_type, n, decoded, row_offset, row_count, out_limit=None):
     out = np.zeros(max(out_limit, 1), dtype=np.uint8)
     r = lib.ixo_handback(sql_type, n, _p(decoded), len(decoded), row_offset, row_count, _p(out), out_limit)
     return out[:max(r, 0)], r
+
+
+def filter_pack(pack, data_type, encode_type, n, op, keys):
+    """ExtIndex_DictBits on one pack -> (result kind or error, bitmap np.uint64[1024]).  keys: ints (numValue) or bytes."""
+    pack = np.ascontiguousarray(pack, dtype=np.uint8)
+    bitmap = np.zeros(1024, dtype=np.uint64)
+    if data_type == STRING:
+        sv = rows_to_bytes(list(keys), STRING)
+        r = lib.ixo_filter(data_type, encode_type, n, _p(pack), len(pack), op, len(keys), None, _p(sv),
+                           bitmap.ctypes.data_as(C.POINTER(C.c_uint64)))
+    else:
+        nv = np.asarray(keys, dtype=np.int64)
+        r = lib.ixo_filter(data_type, encode_type, n, _p(pack), len(pack), op, len(keys), nv.ctypes.data_as(C.POINTER(C.c_int64)),
+                           None, bitmap.ctypes.data_as(C.POINTER(C.c_uint64)))
+    return r, bitmap
