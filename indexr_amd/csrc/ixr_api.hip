@@ -178,7 +178,7 @@ struct ixr_plan {
 };
 
 // Lays the scratch regions of one pack out from obj_count / data_size alone.  Two areas:
-//   index area (kept for the whole plan, filled by one k_parse launch over all packs): DELTA indexes, RLE restart points
+//   index area (kept for the whole plan, filled by one k_parse launch over all packs): DELTA indexes, per-tile RLE segment records
 //   bulk area  (reused group after group): decoded dictionaries, string length arrays, per-row source offsets
 // Offsets are written relative to each area's start; the caller rebases them.  Returns the bytes used in each.
 struct ScratchNeed { uint64_t index, bulk; };

@@ -8,7 +8,7 @@ namespace ixr {
 // Geometry of the VLT DELTA codec (indexr-vlt-segment/.../codec/delta/DeltaCodec.java:31-32) and of the RLE tiling.
 constexpr int kBlock = 128;        // values per delta block (one zig-zag varint minDelta each)
 constexpr int kMini = 32;          // values per mini-block (one width byte each)
-constexpr int kRleTile = 1024;     // rows per RLE restart point / per wave tile in the id-expanding kernels
+constexpr int kRleTile = 1024;     // rows per RLE segment record / per wave tile in the id-expanding kernels
 #ifndef IXR_STR_TILE_ROWS
 #define IXR_STR_TILE_ROWS 256
 #endif

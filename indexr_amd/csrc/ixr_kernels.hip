@@ -17,7 +17,7 @@
 //                LDS window, validates it and leaves an index: per mini-block (offset,width), per block minDelta, per
 //                1024-row tile the RLE segment covering its first row.
 //   k_delta      one workgroup per DELTA stream: bit-unpack + wave/workgroup prefix sum with a running carry.
-//   k_dict_num   one wave per 1024-row tile: expand ids from the restart point, gather dictionary entries, store rows.
+//   k_dict_num   one wave per 1024-row tile: expand ids from the tile's segment record, gather dictionary entries, store rows.
 //   string packs k_str_dict_scan -> k_front_decode -> k_str_index -> k_str_copy  (see each kernel)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
