@@ -80,7 +80,9 @@ __device__ __forceinline__ uint32_t bit_width32(uint32_t v) { return v ? 32u - (
 #endif
 constexpr int kParseLaneThreshold = 16384;  // packs per launch from which k_parse_lanes is used
 constexpr uint32_t kWin = 4096;
-constexpr uint32_t kWinAlloc = kWin + 16;  // bytes of LDS per window (16 spare bytes so that 12-byte peeks never run off)
+constexpr uint32_t kSegTab = 128;                      // short-segment table of the RLE tile expansion (uint2 entries)
+constexpr uint32_t kWinAlloc = kWin + 16 + 8 * kSegTab;  // bytes of LDS per window: data, 16 spare bytes so that 12-byte peeks
+                                                        // never run off, and the segment table
 
 struct Win {
     const uint8_t* base;  // pack start in global memory, 16-byte aligned
@@ -114,6 +116,7 @@ struct Win {
         if (lane == 0) *(uint4*)(lds + kWin) = make_uint4(0, 0, 0, 0);
         wave_lds_sync();
     }
+    __device__ __forceinline__ bool has(uint32_t pos, uint32_t bytes) const { return pos >= w0 && pos + bytes <= w0 + kWin; }
     // make [pos, pos + bytes) part of the window (bytes <= kWin - 16)
     __device__ __forceinline__ void need(uint32_t pos, uint32_t bytes) {
         if (pos < w0 || pos + bytes > w0 + kWin) load(pos);
@@ -139,6 +142,13 @@ struct Win {
         const uint32_t q2 = __builtin_amdgcn_readfirstlane(q[2]);
         const uint64_t lo = (uint64_t)q0 | ((uint64_t)q1 << 32);
         return sh ? ((lo >> sh) | ((uint64_t)q2 << (64 - sh))) : lo;
+    }
+    // 4 bytes at a position that is equal in all lanes, in a scalar register; [pos, pos + 4) must be in the window
+    __device__ __forceinline__ uint32_t peek32u(uint32_t pos) const {
+        const uint32_t idx = pos - w0, a = idx & ~3u, sh = (idx & 3u) * 8u;
+        const uint32_t* q = (const uint32_t*)(lds + a);
+        const uint32_t q0 = __builtin_amdgcn_readfirstlane(q[0]), q1 = __builtin_amdgcn_readfirstlane(q[1]);
+        return (uint32_t)(((uint64_t)q0 | ((uint64_t)q1 << 32)) >> sh);
     }
     // bits [bit, bit + bw) of the bit string starting at pack offset `pos`, bw <= 25; the bytes must be in the window
     __device__ __forceinline__ uint32_t bits(uint32_t pos, uint32_t bit, uint32_t bw) const {
@@ -267,27 +277,33 @@ __device__ int32_t walk_rle(Win& w, uint32_t off, uint32_t len, uint32_t n, uint
     const uint32_t bytew = (bw + 7) >> 3;
     uint32_t o = 0, next_tile = 0;
     int32_t err = 0;
+    const uint32_t vmask = (1u << (8 * bytew)) - 1u;
     while (pos < end) {
-        const uint32_t h = (uint32_t)win_uvarint(w, pos, end, 5, err);
-        if (err) break;
+        // this chain runs on the CU's one scalar unit: keep the common case (one-byte header) short
+        w.need(pos, 16);
+        const uint32_t first4 = w.peek32u(pos);
+        uint32_t h, val = (first4 >> 8) & vmask;  // a run's value follows a one-byte header directly
+        if (!(first4 & 0x80u)) {
+            h = first4 & 0x7Fu;
+            pos++;
+        } else {
+            h = (uint32_t)win_uvarint(w, pos, end, 5, err);
+            if (err) break;
+            val = (uint32_t)w.peek64u(pos) & vmask;  // need(pos, 16) above covers header + value
+        }
         const uint32_t cnt = h >> 1;
         const bool packed = h & 1;
-        const uint64_t payload = packed ? (uint64_t)((cnt + 7) >> 3) * bw : bytew;
-        if ((uint64_t)pos + payload > end || cnt > n - o) { err = E_CORRUPT; break; }
-        if (cnt) {
-            const uint32_t t1 = (o + cnt + kRleTile - 1) / kRleTile;  // tiles [next_tile, t1) start inside this segment
-            if (next_tile < t1) {
-                uint32_t val = 0;
-                if (!packed) {  // the value bytes follow the header; a header is <= 5 bytes, so a fresh 8-byte peek covers them
-                    val = (uint32_t)w.peek64u(pos) & ((1u << (8 * bytew)) - 1u);
-                }
-                const uint4 rec = make_uint4(packed ? pos : pos + bytew, o, cnt, packed ? 1u : (val << 1));
-                for (uint32_t t = next_tile + lane; t < t1; t += 64) restart[t] = rec;
-                next_tile = t1;
-            }
+        if (cnt > n - o) { err = E_CORRUPT; break; }                     // also bounds the product below (cnt <= 65536)
+        const uint32_t payload = packed ? ((cnt + 7) >> 3) * bw : bytew;
+        if (pos + payload > end) { err = E_CORRUPT; break; }
+        const uint32_t t1 = (o + cnt + kRleTile - 1) / kRleTile;  // tiles [next_tile, t1) start inside this segment
+        if (cnt && next_tile < t1) {
+            const uint4 rec = make_uint4(packed ? pos : pos + bytew, o, cnt, packed ? 1u : (val << 1));
+            for (uint32_t t = next_tile + lane; t < t1; t += 64) restart[t] = rec;
+            next_tile = t1;
         }
         o += cnt;
-        pos += (uint32_t)payload;
+        pos += payload;
     }
     if (!err && o != n) err = E_CORRUPT;  // Preconditions.checkState(valIndex == valCount) :126
     return err;
@@ -762,53 +778,85 @@ __device__ __forceinline__ void rle_tile_expand(Win& w, uint32_t bw, uint32_t id
     ids_end = __builtin_amdgcn_readfirstlane(ids_end);
     tile_start = __builtin_amdgcn_readfirstlane(tile_start);
     tile_end = __builtin_amdgcn_readfirstlane(tile_end);
-    const uint32_t bytew = (bw + 7) >> 3;
+    const uint32_t bytew = (bw + 7) >> 3, vmask = (1u << (8 * bytew)) - 1u;  // bytew is 0..2
     // the segment state is the same in every lane: keep it in scalar registers
     uint32_t dpos = __builtin_amdgcn_readfirstlane(seg.x), o = __builtin_amdgcn_readfirstlane(seg.y);
     uint32_t cnt = __builtin_amdgcn_readfirstlane(seg.z);
     const uint32_t sw = __builtin_amdgcn_readfirstlane(seg.w);
     bool packed = sw & 1u;
     uint32_t val = sw >> 1;
+    // Columns with many short runs have ~100 segments per tile.  The chain of headers is inherently serial and runs on the
+    // CU's single scalar unit, shared by all its waves, so the walk does the minimum per segment: short segments (<= 64 rows)
+    // are only noted in a table (x: payload position or run value; y: first row in the tile | rows << 10 | rows to skip << 17 |
+    // packed << 23) and expanded afterwards with one lane per segment.  Long segments are expanded by the whole wave at once.
+    uint2* tab = (uint2*)(w.lds + kWin + 16);
+    uint32_t nseg = 0;
+    auto flush = [&]() {
+        if (nseg == 0) return;
+        Win::wave_lds_sync();
+        for (uint32_t s = lane; s < nseg; s += 64) {
+            const uint2 e = tab[s];
+            const uint32_t r0 = e.y & 1023u, rows = (e.y >> 10) & 127u, skip = (e.y >> 17) & 63u;
+            if ((e.y >> 23) & 1u) {
+                for (uint32_t k = 0; k < rows; k++) ids[r0 + k] = (uint16_t)w.bits(e.x, (skip + k) * bw, bw);
+            } else {
+                for (uint32_t k = 0; k < rows; k++) ids[r0 + k] = (uint16_t)e.x;
+            }
+        }
+        nseg = 0;
+        Win::wave_lds_sync();
+    };
     while (true) {
         const uint32_t lo = max(o, tile_start), hi = min(o + cnt, tile_end);
-        uint32_t next;
-        if (packed) {
-            if (lo < hi) {
+        uint32_t next = packed ? dpos + ((cnt + 7) >> 3) * bw : dpos;
+        if (lo < hi) {
+            if (cnt <= 64u) {
+                if (packed) {  // the segment's payload (<= 128 bytes) must sit in the window when the table is expanded
+                    if (!w.has(dpos, 144u)) { flush(); w.load(dpos); }
+                }
+                if (lane == 0) tab[nseg] = make_uint2(packed ? dpos : val, (lo - tile_start) | ((hi - lo) << 10) | ((lo - o) << 17) | ((uint32_t)packed << 23));
+                nseg++;
+                if (nseg == kSegTab) flush();
+            } else if (packed) {
                 // bytes holding rows [lo, hi) of this segment; at most kRleTile * 16 bits, well inside a window
                 const uint32_t b0 = dpos + (((lo - o) * bw) >> 3);
                 const uint32_t b1 = dpos + (((hi - o) * bw + 7) >> 3);
-                w.need(b0, b1 - b0 + 8);
+                if (!w.has(b0, b1 - b0 + 8)) { flush(); w.load(b0); }
 #pragma unroll 4
                 for (uint32_t i = lo + lane; i < hi; i += 64) ids[i - tile_start] = (uint16_t)w.bits(dpos, (i - o) * bw, bw);
+            } else {
+                for (uint32_t i = lo + lane; i < hi; i += 64) ids[i - tile_start] = (uint16_t)val;
             }
-            next = dpos + ((cnt + 7) >> 3) * bw;
-        } else {
-            for (uint32_t i = lo + lane; i < hi; i += 64) ids[i - tile_start] = (uint16_t)val;
-            next = dpos;
         }
         o += cnt;
         if (o >= tile_end || next >= ids_end) break;
         // next segment header: uvarint (<= 5 bytes, none at or beyond ids_end), then a run's value
-        w.need(next, 16);
-        const uint64_t word = w.peek64u(next);
-        const uint32_t avail = min(5u, ids_end - next);
-        uint32_t h = 0, nb = 0;
-        bool open = true;
+        if (!w.has(next, 16)) { flush(); w.load(next); }
+        const uint32_t first4 = w.peek32u(next);
+        if (!(first4 & 0x80u)) {  // one-byte header: the common case
+            cnt = (first4 & 0x7Fu) >> 1;
+            packed = first4 & 1u;
+            dpos = next + 1;
+            if (!packed) { val = (first4 >> 8) & vmask; dpos += bytew; }
+        } else {
+            const uint64_t word = w.peek64u(next);
+            const uint32_t avail = min(5u, ids_end - next);
+            uint32_t h = 0, nb = 0;
+            bool open = true;
 #pragma unroll
-        for (uint32_t i = 0; i < 5; i++) {
-            const uint32_t b = (uint32_t)(word >> (8 * i)) & 0xFFu;
-            const bool take = open && i < avail;
-            if (take) { h |= (b & 0x7F) << (7 * i); nb = i + 1; }
-            open = take && (b & 0x80);
-        }
-        cnt = h >> 1;
-        packed = h & 1u;
-        dpos = next + nb;
-        if (!packed) {
-            val = (uint32_t)(word >> (8 * nb)) & ((1u << (8 * bytew)) - 1u);  // bytew is 0..2
-            dpos += bytew;
+            for (uint32_t i = 0; i < 5; i++) {
+                const uint32_t b = (uint32_t)(word >> (8 * i)) & 0xFFu;
+                const bool take = open && i < avail;
+                if (take) { h |= (b & 0x7F) << (7 * i); nb = i + 1; }
+                open = take && (b & 0x80);
+            }
+            cnt = h >> 1;
+            packed = h & 1u;
+            dpos = next + nb;
+            if (!packed) { val = (uint32_t)(word >> (8 * nb)) & vmask; dpos += bytew; }
         }
     }
+    flush();
     // the tile's ids were written by this wave only and are read by this wave only
     Win::wave_lds_sync();
 }
