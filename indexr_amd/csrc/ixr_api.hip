@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -23,7 +24,9 @@ using namespace ixr;
 // errors
 // ---------------------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
+static thread_local int32_t g_code = 0;  // code of the last failure on this thread
 static int32_t fail(int32_t code, const char* fmt, ...) {
+    g_code = code;
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
@@ -48,6 +51,13 @@ extern "C" int32_t ixr_device_count(void) {
 }
 
 extern "C" int32_t ixr_init(int32_t device) {
+    // the architecture check is remembered per device (querying the properties costs milliseconds); racing threads at
+    // worst both do the query and store the same answer
+    static std::atomic<int8_t> checked[64];
+    if (device >= 0 && device < 64 && checked[device].load(std::memory_order_acquire) == 1) {
+        HIP_TRY(hipSetDevice(device), return IXR_ERR_HIP);
+        return 0;
+    }
     int n = ixr_device_count();
     if (n <= 0) return fail(IXR_ERR_NO_DEVICE, "no HIP device visible");
     if (device < 0 || device >= n) return fail(IXR_ERR_INVALID_ARGUMENT, "device %d out of range (0..%d)", device, n - 1);
@@ -56,6 +66,7 @@ extern "C" int32_t ixr_init(int32_t device) {
     HIP_TRY(hipGetDeviceProperties(&prop, device), return IXR_ERR_HIP);
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(IXR_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    if (device < 64) checked[device].store(1, std::memory_order_release);
     return 0;
 }
 
@@ -625,7 +636,7 @@ static int32_t single_pack(int32_t device, int32_t data_type, int32_t encode_typ
         dict_cap_override = (uint64_t)in_size;
     }
     ixr_plan* pl = plan_create(device, &d, 1, 0, dict_cap_override);
-    if (!pl) return IXR_ERR_HIP;
+    if (!pl) return g_code < 0 ? g_code : IXR_ERR_HIP;  // plan_create recorded why (no device, bad descriptor, memory)
     DevBuf din, dout;
     const uint64_t in_bytes = align16((uint64_t)in_size) + IXR_IN_SLACK;
     uint64_t out_bytes = align16((uint64_t)std::max(out_limit, 16)) + 16;
