@@ -43,7 +43,7 @@ def parse_args():
     ap.add_argument("--kinds", default="", help="comma-separated synthetic column kinds (kernel experiments; overrides --workload)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xC0FFEE)
     ap.add_argument("--threads", type=int, default=0, help="host threads for input synthesis / CPU baseline")
-    ap.add_argument("--scratch-gib", type=float, default=8.0)
+    ap.add_argument("--scratch-gib", type=float, default=16.0)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU time of each cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--handback", action="store_true", help="also time the engine hand-back (decoded packs -> Spark column vector contents) on the first chunk, checked against the oracle")

@@ -97,7 +97,7 @@ int32_t ixr_stream_synchronize(int32_t device, void* stream);
  * readable for IXR_IN_SLACK bytes past every pack (ixr_plan_in_bytes accounts for it).
  */
 typedef struct ixr_plan ixr_plan;
-/* scratch_budget_bytes: upper bound for the plan's scratch memory (0 = default 8 GiB); packs are processed in
+/* scratch_budget_bytes: upper bound for the plan's scratch memory (0 = default 16 GiB); packs are processed in
  * groups that fit.  Returns NULL on error (see ixr_last_error). */
 ixr_plan* ixr_plan_create(int32_t device, const ixr_pack_desc* descs, int32_t n_packs, uint64_t scratch_budget_bytes);
 void      ixr_plan_destroy(ixr_plan* plan);

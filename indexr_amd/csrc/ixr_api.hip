@@ -134,7 +134,7 @@ extern "C" int32_t ixr_stream_synchronize(int32_t device, void* stream) {
 namespace {
 
 static_assert(kInSlack == IXR_IN_SLACK, "device code and the C ABI must agree on the arena slack");
-constexpr uint64_t kDefaultScratchBudget = 8ull << 30;
+constexpr uint64_t kDefaultScratchBudget = 16ull << 30;
 constexpr int kMaxGroupPacks = 32768;  // grid.y limit is 65535
 
 inline uint64_t align16(uint64_t v) { return (v + 15) & ~15ull; }
