@@ -184,7 +184,7 @@ def main():
         per_launch = dom["alg_bytes_per_step"] * args.steps / max(dom["launches"], 1)
         achieved = per_launch / (dom["avg_ms"] / 1e3) / 1e9 if dom["avg_ms"] > 0 else 0.0
         whole = (plan.total_in + plan.total_out) * args.steps / elapsed / 1e9
-        traffic, traffic_src = pmc_traffic(dom["name"], "%s, %d rows per GPU" % (desc_text, rows))
+        traffic, traffic_src = pmc_traffic(dom["name"], "%s, %d rows per GPU" % (desc_text, rows), dom["launches"] / args.steps)
         roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "alg_bytes_per_launch": int(per_launch), "avg_launch_ms": dom["avg_ms"],
@@ -249,7 +249,7 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(kernel, workload_prefix):
+def pmc_traffic(kernel, workload_prefix, launches_per_pass):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes (hardware counters cannot be read from
     inside this process; tools/profile.sh + tools/pmc_traffic.py produce the file).  None unless the file was measured on
     this very workload."""
@@ -262,9 +262,10 @@ def pmc_traffic(kernel, workload_prefix):
     if not str(doc.get("workload", "")).startswith(workload_prefix):
         return None, None
     k = doc.get("kernels", {}).get(kernel)
-    if not k or not k.get("hbm_bytes_per_launch"):
+    if not k or not k.get("hbm_bytes_per_pass") or launches_per_pass <= 0:
         return None, None
-    return int(k["hbm_bytes_per_launch"]), "profiles/pmc_traffic.json (%s)" % doc.get("source", "")
+    # the counters were summed over one pass of the table; this run may split the pass into a different number of launches
+    return int(k["hbm_bytes_per_pass"] / launches_per_pass), "profiles/pmc_traffic.json (%s)" % doc.get("source", "")
 
 
 def time_cpu_oracle(np, sample, threads, target_s, log):

@@ -15,6 +15,9 @@ import sys
 from collections import defaultdict
 
 
+PASSES = 3  # decode passes in one counter run of tools/profile.sh
+
+
 def short(name):
     m = re.match(r"(?:void )?(?:ixr::)?(k_\w+)(<[^>]*>)?", name)
     if not m:
@@ -64,6 +67,8 @@ def main():
         }
         r, wv = kernels[k]["read_bytes_per_launch"], kernels[k]["write_bytes_per_launch"]
         kernels[k]["hbm_bytes_per_launch"] = (r or 0.0) + (wv or 0.0)
+        # tools/profile.sh runs the counter passes with --steps 2 --warmup 1: three passes over the table
+        kernels[k]["hbm_bytes_per_pass"] = kernels[k]["hbm_bytes_per_launch"] * kernels[k]["launches_counted"] / PASSES
     doc = {
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); read = 2 * FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB",
         "workload": bench["config"]["workload"] if bench else None,
