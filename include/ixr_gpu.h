@@ -148,13 +148,18 @@ int32_t ixr_get_data_from_dict_struct(int32_t device, int32_t data_type, int32_t
 /* ---- predicate evaluation on dictionary ids ---------------------------------------------------------------------
  * Replaces, for every DICT_COMPRESS pack of the plan at once, the per-pack filters of ExtIndex_DictBits
  * (indexr-vlt-segment/src/main/java/io/indexr/vlt/segment/index/ExtIndex_DictBits.java): equal :60-79, in :81-113,
- * greater :115-145, between :147-180.  A key is looked up in the pack's sorted dictionary (searchEntry :33-58,
- * BinarySearch.java) and the rows' ids are compared; rows are never materialised.  `like` (:182-200) works on decoded
- * strings, not on ids, and is not provided.
+ * greater :115-145, between :147-180, like :182-200.  A key is looked up in the pack's sorted dictionary (searchEntry
+ * :33-58, BinarySearch.java) and the rows' ids are compared; rows are never materialised.  LIKE matches its pattern
+ * (SQLLike.match, indexr-common/src/main/java/io/indexr/util/SQLLike.java:12-94: % any run of bytes, _ one byte,
+ * backslash escapes) against every dictionary entry once and marks the rows whose id matched, which selects the same
+ * rows as the reference's match on every row's string; string packs only, a numeric pack answers
+ * IXR_ERR_UNSUPPORTED_TYPE where the reference throws IllegalStateException (:198); the result is NONE or SOME, never
+ * ALL (fixBitmapInPack, indexr-segment/src/main/java/io/indexr/segment/PackExtIndex.java:32-39).
  *   filters[i]   the predicate for pack i of the plan
  *   values       host buffer holding the keys, values_off bytes in (multiple of 8): numeric packs: n_values x int64, the
  *                reference's `long numValue` (INT/LONG: the value; FLOAT/DOUBLE: the raw long bits of the key as a
- *                double, :44,47); string packs: a StringsStruct of the n_values keys (int32 off[n_values+1] | bytes)
+ *                double, :44,47); string packs, and the pattern of a LIKE: a StringsStruct of the n_values keys (int32
+ *                off[n_values+1] | bytes)
  *   d_bitmaps    device memory, IXR_BITMAP_BYTES per pack: 1024 little-endian 64-bit words, row r = bit r & 63 of word
  *                r >> 6 (BitMap / DirectBitMap, indexr-common/.../util/DirectBitMap.java); all 1024 words are written
  *   results[i]   IXR_BITMAP_NONE / IXR_BITMAP_ALL (the reference returns its constants; the bitmap is all zeros / ones up to
@@ -163,12 +168,13 @@ int32_t ixr_get_data_from_dict_struct(int32_t device, int32_t data_type, int32_t
  *                Preconditions.checkState fails (between :165-166), decode errors as in ixr_plan_status
  * The call synchronises with `stream`.  Returns the number of packs with a negative result, or a negative library error.
  */
-enum { IXR_FILTER_EQUAL = 1, IXR_FILTER_IN = 2, IXR_FILTER_GREATER = 3, IXR_FILTER_GREATER_EQUAL = 4, IXR_FILTER_BETWEEN = 5 };
+enum { IXR_FILTER_EQUAL = 1, IXR_FILTER_IN = 2, IXR_FILTER_GREATER = 3, IXR_FILTER_GREATER_EQUAL = 4, IXR_FILTER_BETWEEN = 5,
+       IXR_FILTER_LIKE = 6 };
 enum { IXR_BITMAP_NONE = 0, IXR_BITMAP_ALL = 1, IXR_BITMAP_SOME = 2 };
 #define IXR_BITMAP_BYTES 8192
 typedef struct ixr_filter_desc {
     int32_t  op;         /* IXR_FILTER_* */
-    int32_t  n_values;   /* EQUAL, GREATER, GREATER_EQUAL: 1; BETWEEN: 2; IN: >= 1 */
+    int32_t  n_values;   /* EQUAL, GREATER, GREATER_EQUAL, LIKE: 1; BETWEEN: 2; IN: >= 1 */
     uint64_t values_off; /* where this pack's keys start in `values`, multiple of 8 */
 } ixr_filter_desc;
 int32_t ixr_plan_run_filter(ixr_plan* plan, const void* d_in, uint64_t in_bytes, const ixr_filter_desc* filters,

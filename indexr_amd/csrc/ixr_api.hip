@@ -761,7 +761,7 @@ extern "C" int32_t ixr_handback_run(int32_t device, const ixr_handback_desc* des
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// predicate evaluation on dictionary ids (ExtIndex_DictBits.java:33-180)
+// predicate evaluation on dictionary ids (ExtIndex_DictBits.java:33-200)
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" int32_t ixr_plan_run_filter(ixr_plan* pl, const void* d_in, uint64_t in_bytes, const ixr_filter_desc* filters,
                                        const void* values, uint64_t values_bytes, void* d_bitmaps, uint64_t bitmap_bytes,
@@ -774,15 +774,19 @@ extern "C" int32_t ixr_plan_run_filter(ixr_plan* pl, const void* d_in, uint64_t 
     // host-side checks of what the kernels will index with: key ranges inside the value buffer
     std::vector<DevFilter> hf((size_t)pl->n);
     uint64_t n_keys = 0;
+    bool any_like = false;
     for (int i = 0; i < pl->n; i++) {
         const ixr_filter_desc& f = filters[i];
+        any_like |= f.op == IXR_FILTER_LIKE;
         const bool str = pl->descs[(size_t)i].data_type == IXR_STRING;
-        if (f.op < IXR_FILTER_EQUAL || f.op > IXR_FILTER_BETWEEN || f.n_values < 1 || f.n_values > (1 << 20) || (f.values_off & 7) ||
-            (f.op == IXR_FILTER_BETWEEN && f.n_values < 2))
+        if (f.op < IXR_FILTER_EQUAL || f.op > IXR_FILTER_LIKE || f.n_values < 1 || f.n_values > (1 << 20) || (f.values_off & 7) ||
+            (f.op == IXR_FILTER_BETWEEN && f.n_values < 2) || (f.op == IXR_FILTER_LIKE && f.n_values != 1))
             return fail(IXR_ERR_INVALID_ARGUMENT, "filter %d: bad op, value count or offset", i);
-        uint64_t need = str ? 4ull * ((uint64_t)f.n_values + 1) : 8ull * (uint64_t)f.n_values;
+        // a LIKE pattern is a StringsStruct whatever the pack's type (a numeric pack answers IXR_ERR_UNSUPPORTED_TYPE)
+        const bool str_keys = str || f.op == IXR_FILTER_LIKE;
+        uint64_t need = str_keys ? 4ull * ((uint64_t)f.n_values + 1) : 8ull * (uint64_t)f.n_values;
         if (f.values_off + need > values_bytes) return fail(IXR_ERR_INVALID_ARGUMENT, "filter %d: keys outside the value buffer", i);
-        if (str) {
+        if (str_keys) {
             const int32_t* off = (const int32_t*)((const uint8_t*)values + f.values_off);
             for (int v = 0; v < f.n_values; v++)
                 if (off[v] < 0 || off[v + 1] < off[v]) return fail(IXR_ERR_INVALID_ARGUMENT, "filter %d: key offsets not ascending", i);
@@ -792,7 +796,8 @@ extern "C" int32_t ixr_plan_run_filter(ixr_plan* pl, const void* d_in, uint64_t 
         DevFilter& d = hf[(size_t)i];
         d.op = f.op; d.n_values = f.n_values; d.values_off = f.values_off; d.match_off = (uint32_t)n_keys;
         d.result = IXR_ERR_BUG; d.from = d.to = d.n_match = d.pad = 0;
-        n_keys += (uint64_t)f.n_values;
+        // matched ids: at most one per key; LIKE can match every dictionary entry, and a pack has at most objCount of them
+        n_keys += f.op == IXR_FILTER_LIKE ? (uint64_t)std::max(pl->descs[(size_t)i].obj_count, 1) : (uint64_t)f.n_values;
     }
     HIP_TRY(hipSetDevice(pl->device), return IXR_ERR_HIP);
     hipStream_t st = (hipStream_t)stream;
@@ -836,6 +841,7 @@ extern "C" int32_t ixr_plan_run_filter(ixr_plan* pl, const void* d_in, uint64_t 
             run_group_front_num(pl, T, c, g);
             run_group_front_str(pl, T, c, g, 1);
             T.run("k_filter_search", g.cnt[L_ALL], [&] { launch_filter_search(c, L + g.off[L_ALL], g.cnt[L_ALL], d_f, d_vals, d_match); });
+            if (any_like) T.run("k_filter_like", g.cnt[L_ALL], [&] { launch_filter_like(c, L + g.off[L_ALL], g.cnt[L_ALL], d_f, d_vals, d_match); });
             T.run("k_filter_rows", g.cnt[L_ALL], [&] { launch_filter_rows(c, L + g.off[L_ALL], g.cnt[L_ALL], d_f, d_match, (unsigned long long*)d_bitmaps); });
         }
         if (hipGetLastError() != hipSuccess) rc = fail(IXR_ERR_HIP, "kernel launch failed");

@@ -28,7 +28,7 @@
 namespace ixr {
 
 // error codes (mirror include/ixr_gpu.h)
-constexpr int32_t E_OVERFLOW = -1, E_CORRUPT = -2, E_ILLEGAL_ENC = -101;
+constexpr int32_t E_OVERFLOW = -1, E_CORRUPT = -2, E_ILLEGAL_ENC = -101, E_UNSUPPORTED_TYPE = -102;
 
 // ---------------------------------------------------------------------------------------------------------------
 // unaligned little-endian access built from aligned dword loads (the arena is readable 16 bytes past every pack)
@@ -1703,10 +1703,11 @@ __global__ __launch_bounds__(256) void k_ds_rows(const DevPack* __restrict__ pac
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Predicate evaluation on dictionary ids (ExtIndex_DictBits.java:33-180).
+// Predicate evaluation on dictionary ids (ExtIndex_DictBits.java:33-200).
 //   k_filter_search  one wave per pack: looks the keys up in the decoded dictionary (BinarySearch.java: plain < and > on the
 //                    entry type, unsigned bytes then length for strings), one key per lane, and reduces them to what the
-//                    row pass needs: NONE / ALL, an id range [from, to), or a list of matched ids.
+//                    row pass needs: NONE / ALL, an id range [from, to), or a list of matched ids.  `like` (:182-200)
+//                    is left to k_filter_like: the pattern against every dictionary entry, one workgroup per pack.
 //   k_filter_rows    one wave per 1024-row tile: expands the ids, tests them (range compare, or a bit mask over the
 //                    dictionary entries in LDS for id lists), ballots 64 rows into one bitmap word.
 // ---------------------------------------------------------------------------------------------------------------
@@ -1735,6 +1736,34 @@ __device__ __forceinline__ int search_str(const uint32_t* doff, const uint8_t* b
         else return mid;
     }
     return -(from + 1);
+}
+
+// SQLLike.match (indexr-common/src/main/java/io/indexr/util/SQLLike.java:12-94): % any run of bytes, _ one byte, \\ takes the
+// next pattern byte literally.  The reference recurses over every split point of a %; whether some split matches is what
+// the loop below finds by going back to the last % and letting it take one more byte, without a stack.
+__device__ __forceinline__ bool like_match(const uint8_t* s, int slen, const uint8_t* p, int plen) {
+    int si = 0, pi = 0, star_p = -1, star_s = 0;
+    for (;;) {
+        if (si >= slen) {  // :28-36: only % may be left
+            while (pi < plen && p[pi] == '%') pi++;
+            return pi >= plen;
+        }
+        if (pi < plen) {
+            const uint8_t c = p[pi];
+            if (c == '\\') {  // :49-53 then :83-91; a trailing escape never matches (:39-41)
+                if (pi + 1 < plen && p[pi + 1] == s[si]) { si++; pi += 2; continue; }
+            } else if (c == '_') {  // :54-58
+                si++; pi++; continue;
+            } else if (c == '%') {  // :59-79
+                star_p = pi; star_s = si; pi++; continue;
+            } else if (c == s[si]) {
+                si++; pi++; continue;
+            }
+        }
+        if (star_p < 0) return false;
+        si = ++star_s;
+        pi = star_p + 1;
+    }
 }
 
 __global__ __launch_bounds__(64) void k_filter_search(const DevPack* __restrict__ packs, const int* __restrict__ list,
@@ -1793,8 +1822,69 @@ __global__ __launch_bounds__(64) void k_filter_search(const DevPack* __restrict_
             if (!(from >= 0 && from < ec) || !(to >= 0 && to <= ec)) F.result = -100;  // Preconditions.checkState :165-166
             else F.result = to - from <= 0 ? 0 : (to - from >= ec ? 1 : 2);
         }
+    } else if (op == 6) {  // like: k_filter_like
     } else if (lane == 0) {
         F.result = -1000;
+    }
+}
+
+// like :182-200: a row matches when its dictionary entry does.  One workgroup per pack, one entry per thread and round;
+// a round's entries lie next to each other in the dictionary body and are staged in LDS when they fit (the matcher reads
+// byte after byte, each read waiting for the one before).  The ids of the matching entries are appended to the pack's
+// match list in no particular order.
+constexpr int kLikeThreads = 512, kLikeLds = 40960, kLikePat = 256;
+__global__ __launch_bounds__(kLikeThreads) void k_filter_like(const DevPack* __restrict__ packs, const int* __restrict__ list,
+                                                              const PackMeta* __restrict__ metas, const uint8_t* __restrict__ scratch,
+                                                              DevFilter* __restrict__ filters, const uint8_t* __restrict__ values,
+                                                              uint32_t* __restrict__ matches) {
+    __shared__ uint32_t s_total;
+    __shared__ __align__(16) uint8_t s_body[kLikeLds + 16];
+    __shared__ uint8_t s_pat[kLikePat];
+    const int pi = list[blockIdx.x], lane = threadIdx.x & 63;
+    const DevPack& P = packs[pi];
+    const PackMeta& M = metas[pi];
+    DevFilter& F = filters[pi];
+    if (F.op != 6 || M.status < 0 || P.encode_type != 6 || (M.kind != K_DICT_NUM && M.kind != K_DICT_STR)) return;  // k_filter_search answered
+    if (P.width != 0) { if (threadIdx.x == 0) F.result = E_UNSUPPORTED_TYPE; return; }  // "column type ... is illegal in LIKE"
+    const int ec = (int)M.entry_count;
+    const uint8_t* dict = scratch + P.s_dict;
+    const uint8_t* vals = values + F.values_off;
+    const int32_t* koff = (const int32_t*)vals;
+    const uint8_t* pat = vals + 8 + koff[0];
+    const int plen = koff[1] - koff[0];
+    const uint32_t* doff = (const uint32_t*)dict;
+    const uint8_t* body = dict + 4ull * ((uint32_t)ec + 1);  // 4-byte aligned: the dictionary slot is 16-byte aligned
+    const bool pat_lds = plen <= kLikePat;
+    if (threadIdx.x == 0) s_total = 0;
+    if (pat_lds) for (int i = threadIdx.x; i < plen; i += kLikeThreads) s_pat[i] = pat[i];
+    for (int e0 = 0; e0 < ec; e0 += kLikeThreads) {  // workgroup-uniform trip count
+        const uint32_t lo = doff[e0], hi = doff[min(e0 + kLikeThreads, ec)];
+        const uint32_t lo4 = lo & ~3u;  // body + lo4 is 4-byte aligned
+        const bool staged = hi - lo4 <= (uint32_t)kLikeLds;
+        __syncthreads();  // the round before is done with s_body; s_total / s_pat are written
+        if (staged) {
+            for (uint32_t i = threadIdx.x * 4; i < hi - lo4; i += kLikeThreads * 4)
+                *(uint32_t*)(s_body + i) = *(const uint32_t*)(body + lo4 + i);  // may read up to 3 bytes past hi: inside the slot's slack
+            __syncthreads();
+        }
+        const int e = e0 + (int)threadIdx.x;
+        bool hit = false;
+        if (e < ec) {
+            const uint32_t a = doff[e], len = doff[e + 1] - a;
+            if (staged && pat_lds) hit = like_match(s_body + (a - lo4), (int)len, s_pat, plen);
+            else if (staged) hit = like_match(s_body + (a - lo4), (int)len, pat, plen);
+            else hit = like_match(body + a, (int)len, pat, plen);
+        }
+        const uint64_t m = __ballot(hit);
+        uint32_t base = 0;
+        if (lane == 0 && m) base = atomicAdd(&s_total, (uint32_t)__popcll(m));
+        base = __shfl(base, 0);
+        if (hit) matches[F.match_off + base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)e;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        F.n_match = s_total;
+        F.result = s_total == 0 ? 0 : 2;  // fixBitmapInPack (PackExtIndex.java:32-39): empty -> NONE, never ALL
     }
 }
 
@@ -1813,7 +1903,7 @@ __global__ __launch_bounds__(256) void k_filter_rows(const DevPack* __restrict__
     const uint32_t n = (uint32_t)P.obj_count;
     const uint32_t tile = blockIdx.x * 4 + wave, tile_start = tile * kRleTile;
     unsigned long long* words = bitmaps + (size_t)pi * 1024 + tile * 16;
-    const bool by_set = F.result == 2 && (F.op == 1 || F.op == 2);
+    const bool by_set = F.result == 2 && (F.op == 1 || F.op == 2 || F.op == 6);
     if (by_set) {  // workgroup-uniform
         const uint32_t ew = (M.entry_count + 31) / 32;
         for (uint32_t i = threadIdx.x; i < ew; i += 256) s_emask[i] = 0;
@@ -2044,6 +2134,10 @@ void launch_ds_rows(const LaunchCtx& c, const int* list, int count, int mode) {
 void launch_filter_search(const LaunchCtx& c, const int* list, int count, DevFilter* filters, const uint8_t* values, uint32_t* matches) {
     if (count <= 0) return;
     hipLaunchKernelGGL(k_filter_search, dim3(count), dim3(64), 0, c.stream, c.packs, list, c.metas, c.scratch, filters, values, matches);
+}
+void launch_filter_like(const LaunchCtx& c, const int* list, int count, DevFilter* filters, const uint8_t* values, uint32_t* matches) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_filter_like, dim3(count), dim3(kLikeThreads), 0, c.stream, c.packs, list, c.metas, c.scratch, filters, values, matches);
 }
 void launch_filter_rows(const LaunchCtx& c, const int* list, int count, DevFilter* filters, const uint32_t* matches,
                         unsigned long long* bitmaps) {

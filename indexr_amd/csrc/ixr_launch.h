@@ -49,6 +49,7 @@ struct DevFilter {
     uint32_t pad;
 };
 void launch_filter_search(const LaunchCtx& c, const int* list, int count, DevFilter* filters, const uint8_t* values, uint32_t* matches);
+void launch_filter_like(const LaunchCtx& c, const int* list, int count, DevFilter* filters, const uint8_t* values, uint32_t* matches);
 void launch_filter_rows(const LaunchCtx& c, const int* list, int count, DevFilter* filters, const uint32_t* matches,
                         unsigned long long* bitmaps);
 

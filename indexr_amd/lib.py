@@ -55,7 +55,7 @@ class FilterDesc(C.Structure):
     _fields_ = [("op", C.c_int32), ("n_values", C.c_int32), ("values_off", C.c_uint64)]
 
 
-FILTER_EQUAL, FILTER_IN, FILTER_GREATER, FILTER_GREATER_EQUAL, FILTER_BETWEEN = 1, 2, 3, 4, 5
+FILTER_EQUAL, FILTER_IN, FILTER_GREATER, FILTER_GREATER_EQUAL, FILTER_BETWEEN, FILTER_LIKE = 1, 2, 3, 4, 5, 6
 BITMAP_NONE, BITMAP_ALL, BITMAP_SOME = 0, 1, 2
 BITMAP_BYTES = 8192
 

@@ -1166,6 +1166,42 @@ static int search_entry(int data_type, const uint8_t* entries, int ec, int64_t n
     return -(from + 1);
 }
 
+/* SQLLike.match (indexr-common/src/main/java/io/indexr/util/SQLLike.java:12-94), the recursion as it stands: % any
+ * sequence, _ one byte, \\ escapes the next pattern byte. */
+static int like_match(const uint8_t* str, int sLen, const uint8_t* pat, int pLen, int sNdx, int pNdx) {
+    if (pLen == 1 && pat[0] == '%') return 1;
+    int nextIsNotWildcard = 0;
+    for (;;) {
+        if (sNdx >= sLen) {
+            while (pNdx < pLen && pat[pNdx] == '%') pNdx++;
+            return pNdx >= pLen;
+        }
+        if (pNdx >= pLen) return 0;
+        const uint8_t p = pat[pNdx];
+        if (!nextIsNotWildcard) {
+            if (p == '\\') { pNdx++; nextIsNotWildcard = 1; continue; }
+            if (p == '_') { sNdx++; pNdx++; continue; }
+            if (p == '%') {
+                uint8_t pNext = 0;
+                if (pNdx + 1 < pLen) pNext = pat[pNdx + 1];
+                if (pNext == '%') { pNdx++; continue; }
+                pNdx++;
+                for (int i = sLen; i >= sNdx; i--)
+                    if (like_match(str, sLen, pat, pLen, i, pNdx)) return 1;
+                return 0;
+            }
+        } else {
+            nextIsNotWildcard = 0;
+        }
+        if (p != str[sNdx]) return 0;
+        sNdx++;
+        pNdx++;
+    }
+}
+int ixo_like(const uint8_t* str, int str_len, const uint8_t* pattern, int pattern_len) {
+    return like_match(str, str_len, pattern, pattern_len, 0, 0);
+}
+
 int ixo_filter(int data_type, int encode_type, int n, const uint8_t* pack, int pack_size, int op, int n_values,
                const int64_t* num_values, const uint8_t* str_values, uint64_t* bitmap) {
     if (encode_type != IXO_DICT_COMPRESS) return IXO_DATA_IMPROPER;  /* only dict-encoded packs get ExtIndex_DictBits */
@@ -1223,6 +1259,17 @@ int ixo_filter(int data_type, int encode_type, int n, const uint8_t* pack, int p
         else if (to - from <= 0) result = 0;
         else if (to - from >= ec) result = 1;
         else for (int i = 0; i < n; i++) { const int id = ld32(ids + ((size_t)i << 2)); if (id >= from && id < to) bitmap[i >> 6] |= 1ull << (i & 63); }
+    } else if (op == 6) {  /* like (:182-200): SQLLike.match on every row's string; fixBitmapInPack: empty -> NONE */
+        if (data_type != IXO_STRING) { free(ds); return -102; }  /* "column type ... is illegal in LIKE" */
+        KEY(0, kp, kl);
+        const uint8_t* body = entries + 4 * ((size_t)ec + 1);
+        int any = 0;
+        for (int i = 0; i < n; i++) {
+            const int id = ld32(ids + ((size_t)i << 2));
+            const int32_t a = ld32(entries + 4 * (size_t)id), b = ld32(entries + 4 * (size_t)(id + 1));
+            if (like_match(body + a, b - a, kp, kl, 0, 0)) { bitmap[i >> 6] |= 1ull << (i & 63); any = 1; }
+        }
+        if (!any) result = 0;
     } else {
         result = -1000;
     }

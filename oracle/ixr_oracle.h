@@ -92,10 +92,12 @@ int ixo_handback(int sql_type, int n, const uint8_t* decoded, int data_size, int
 /* ---- predicate evaluation on dictionary ids ----
  * Restates ExtIndex_DictBits (indexr-vlt-segment/.../vlt/segment/index/ExtIndex_DictBits.java:33-180) over the pack's
  * DictStruct: op 1 equal (:60-79), 2 in (:81-113), 3 greater (:115-145, acceptEqual = false), 4 greater with acceptEqual,
- * 5 between (:147-180).  num_values: the reference's long numValue per key (INT/LONG: the value; FLOAT/DOUBLE: raw long bits
+ * 5 between (:147-180), 6 like (:182-200; string packs only, else -102).  num_values: the reference's long numValue per key (INT/LONG: the value; FLOAT/DOUBLE: raw long bits
  * of the key as a double, :44,47); str_values: a StringsStruct of the keys.  bitmap: 1024 little-endian 64-bit words
  * (BitMap / DirectBitMap: row i is bit i & 63 of word i >> 6).  Returns 0 NONE, 1 ALL, 2 a bitmap; -100 where the reference's
  * Preconditions.checkState fails (:165-166); -3 when the pack is not DICT_COMPRESS; other negatives: decode errors. */
+/* SQLLike.match(string, pattern) (indexr-common/.../util/SQLLike.java:12-94): 1 when the string matches. */
+int ixo_like(const uint8_t* str, int str_len, const uint8_t* pattern, int pattern_len);
 int ixo_filter(int data_type, int encode_type, int n, const uint8_t* pack, int pack_size, int op, int n_values,
                const int64_t* num_values, const uint8_t* str_values, uint64_t* bitmap);
 

@@ -1,6 +1,8 @@
-"""Predicate evaluation on dictionary ids (ExtIndex_DictBits.java:33-180).
+"""Predicate evaluation on dictionary ids (ExtIndex_DictBits.java:33-200).
 CPU: the oracle against a direct numpy statement of "which rows satisfy the predicate" (for keys where dictionary search
 and value comparison agree: no NaN / -0.0 keys).  GPU: the device path against the oracle, bit for bit, for every op."""
+import ctypes as C
+import re
 import struct
 
 import numpy as np
@@ -78,6 +80,76 @@ def predicates_for(dt, rows):
     return out
 
 
+def like_regex(pattern):
+    """SQLLike.match (SQLLike.java:12-94) said as a regular expression over bytes: % -> .*, _ -> ., backslash takes the next
+    byte literally; a pattern ending in a lone backslash matches nothing."""
+    out, i = [], 0
+    while i < len(pattern):
+        c = pattern[i:i + 1]
+        if c == b"\\":
+            if i + 1 >= len(pattern):
+                return re.compile(b"(?!)")
+            out.append(re.escape(pattern[i + 1:i + 2]))
+            i += 2
+            continue
+        out.append(b".*" if c == b"%" else b"." if c == b"_" else re.escape(c))
+        i += 1
+    return re.compile(b"".join(out), re.DOTALL)
+
+
+def oracle_like(s, p):
+    O.lib.ixo_like.restype = C.c_int
+    return bool(O.lib.ixo_like(C.c_char_p(s), len(s), C.c_char_p(p), len(p)))
+
+
+LIKE_PATTERNS = [b"www.s1%", b"%/25_", b"%", b"%%", b"nomatch%", b"www.s_.com/%", b"%s2%.com%7", b"www.s0.com/0", b"", b"_",
+                 b"%w%w%w%.%c%m%/%1%", b"www.s3.com/1__", b"%\\%%", b"%\\_%", b"www%\\", b"%.com/%%%5", b"_ww.s%"]
+
+
+def like_column(n, rng):
+    """strings around the wildcard and escape bytes themselves, the empty string included"""
+    alphabet = [b"a", b"b", b"%", b"_", b"\\", b"ab", b""]
+    pool = sorted(set(b"".join(alphabet[j] for j in rng.integers(0, len(alphabet), rng.integers(0, 7))) for _ in range(400)))
+    return [pool[i] for i in rng.integers(0, len(pool), n)], pool
+
+
+def test_oracle_like_agrees_with_the_regular_expression_reading():
+    rng = np.random.default_rng(99)
+    atoms = [b"a", b"b", b"%", b"_", b"\\", b"c"]
+    fixed = [(b"windows", b"win%", True), (b"windows", b"%dow_", True), (b"mac", b"win%", False), (b"", b"%", True), (b"", b"", True),
+             (b"a%b", b"a\\%b", True), (b"axb", b"a\\%b", False), (b"abc", b"____", False), (b"abc", b"abc\\", False), (b"a_c", b"a\\_c", True),
+             (b"a\\c", b"a\\\\c", True), (b"aaaaaaaaaaaaaaaaaaaab", b"%a%a%a%a%a%a%a%a%a%c", False)]
+    for s_, p_, want in fixed:
+        assert oracle_like(s_, p_) == want, (s_, p_)
+        assert bool(like_regex(p_).fullmatch(s_)) == want, (s_, p_)
+    for _ in range(4000):
+        s_ = b"".join(atoms[j] for j in rng.integers(0, len(atoms), rng.integers(0, 9)))
+        p_ = b"".join(atoms[j] for j in rng.integers(0, len(atoms), rng.integers(0, 7)))
+        assert oracle_like(s_, p_) == bool(like_regex(p_).fullmatch(s_)), (s_, p_)
+
+
+def test_oracle_like_filter_marks_the_rows_whose_string_matches():
+    rng = np.random.default_rng(5)
+    n = 6000
+    for rows in (make_columns(n, rng)[O.STRING], like_column(n, rng)[0]):
+        pack, et = O.compress_pack(O.rows_to_bytes(rows, O.STRING), O.STRING, n, True)
+        assert et == O.DICT_COMPRESS
+        kinds = set()
+        for pat in LIKE_PATTERNS + [b"a%", b"%b", b"\\%%", b"\\\\%", b"_\\__"]:
+            rx = like_regex(pat)
+            mask = np.array([rx.fullmatch(v) is not None for v in rows])
+            r, bm = O.filter_pack(pack, O.STRING, et, n, L.FILTER_LIKE, [pat])
+            kinds.add(r)
+            if not mask.any():
+                assert r == L.BITMAP_NONE, pat
+            else:  # never ALL: the bitmap comes back as it is (fixBitmapInPack)
+                assert r == L.BITMAP_SOME and np.array_equal(bm, bitmap_of(mask)), pat
+        assert kinds == {L.BITMAP_NONE, L.BITMAP_SOME}
+    ints = np.arange(500, dtype="<i4") % 7
+    p1, e1 = O.compress_pack(O.rows_to_bytes(ints, O.INT), O.INT, 500, True)
+    assert O.filter_pack(p1, O.INT, e1, 500, L.FILTER_LIKE, [0])[0] == -102  # "column type ... is illegal in LIKE"
+
+
 def expected_kind(mask):
     return L.BITMAP_NONE if not mask.any() else None  # ALL / SOME depends on the dictionary shortcut, not only on the rows
 
@@ -135,14 +207,23 @@ def test_gpu_filter_matches_oracle_for_every_op_and_type():
             if dt in (O.FLOAT, O.DOUBLE):
                 plist.append((L.FILTER_EQUAL, [dbits(float("nan"))], None))
                 plist.append((L.FILTER_GREATER_EQUAL, [dbits(-0.0)], None))
+            if dt == O.STRING:
+                plist += [(L.FILTER_LIKE, [pat], None) for pat in LIKE_PATTERNS]
             for op, keys, _ in plist:
                 cases.append(G.Case(pack, dt, et, n, len(data)))
                 preds.append((op, keys))
+        wild, _ = like_column(n, rng)
+        wdata = O.rows_to_bytes(wild, O.STRING)
+        wpack, wet = O.compress_pack(wdata, O.STRING, n, True)
+        for pat in LIKE_PATTERNS + [b"a%", b"%b", b"\\%%", b"\\\\%", b"_\\__", b"%a%b%a%b%\\%%_"]:
+            cases.append(G.Case(wpack, O.STRING, wet, n, len(wdata)))
+            preds.append((L.FILTER_LIKE, [pat]))
     # one entry dictionaries (ALL shortcut of equal), a DELTA pack and a corrupted pack
     one = np.full(300, 42, dtype="<i4")
     p1, e1 = O.compress_pack(O.rows_to_bytes(one, O.INT), O.INT, 300, True)
     cases.append(G.Case(p1, O.INT, e1, 300, 1200)); preds.append((L.FILTER_EQUAL, [42]))
     cases.append(G.Case(p1, O.INT, e1, 300, 1200)); preds.append((L.FILTER_IN, [42, 43]))
+    cases.append(G.Case(p1, O.INT, e1, 300, 1200)); preds.append((L.FILTER_LIKE, [b"4%"]))  # numeric column: rejected
     seq = np.arange(70000, 70000 + 40000, dtype="<i4")
     p2 = O.compress_pack_as(O.rows_to_bytes(seq, O.INT), O.INT, 40000, O.DELTA)
     cases.append(G.Case(p2, O.INT, O.DELTA, 40000, 160000)); preds.append((L.FILTER_EQUAL, [70001]))
@@ -151,7 +232,7 @@ def test_gpu_filter_matches_oracle_for_every_op_and_type():
 
     descs, arena, _ = G.build_arena(cases)
     plan = L.Plan(0, descs, 64 << 20)  # small scratch budget: several groups
-    values, offs = L.filter_keys([k for _, k in preds], [c.data_type == O.STRING for c in cases])
+    values, offs = L.filter_keys([k for _, k in preds], [c.data_type == O.STRING or op == L.FILTER_LIKE for c, (op, _) in zip(cases, preds)])
     filters = [L.FilterDesc(op, len(k), o) for (op, k), o in zip(preds, offs)]
     d_in = L.DeviceBuffer(0, len(arena))
     d_bm = L.DeviceBuffer(0, L.BITMAP_BYTES * len(cases))
@@ -162,7 +243,8 @@ def test_gpu_filter_matches_oracle_for_every_op_and_type():
         host = d_bm.download().view("<u8").reshape(len(cases), 1024)
         kinds = set()
         for i, (c, (op, keys)) in enumerate(zip(cases, preds)):
-            want, bm = O.filter_pack(c.pack, c.data_type, c.encode_type, c.n, op, keys)
+            okeys = [0] if (op == L.FILTER_LIKE and c.data_type != O.STRING) else keys
+            want, bm = O.filter_pack(c.pack, c.data_type, c.encode_type, c.n, op, okeys)
             if i == len(cases) - 1:
                 assert res[i] < 0  # the corrupted pack: some decode error
                 continue
@@ -174,7 +256,7 @@ def test_gpu_filter_matches_oracle_for_every_op_and_type():
                 assert np.array_equal(host[i], bitmap_of(np.ones(c.n, dtype=bool))), i
             else:
                 assert not host[i].any(), i
-        assert kinds >= {L.BITMAP_NONE, L.BITMAP_ALL, L.BITMAP_SOME, -100, O.DATA_IMPROPER}
+        assert kinds >= {L.BITMAP_NONE, L.BITMAP_ALL, L.BITMAP_SOME, -100, -102, O.DATA_IMPROPER}
         assert nbad == sum(1 for r in res if r < 0)
     finally:
         plan.destroy()
