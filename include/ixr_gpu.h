@@ -181,6 +181,34 @@ int32_t ixr_plan_run_filter(ixr_plan* plan, const void* d_in, uint64_t in_bytes,
                             const void* values, uint64_t values_bytes, void* d_bitmaps, uint64_t bitmap_bytes,
                             int32_t* results, void* stream);
 
+/* ---- predicates on the rows of decoded packs ----------------------------------------------------------------------
+ * What packs without a dictionary get in the reference: ExtIndex_SimpleBits
+ * (indexr-segment/src/main/java/io/indexr/segment/index/ExtIndex_SimpleBits.java): equal :25-89, in :91-166, greater
+ * :168-234, between :236-311, like :313-331 (VersionAdapter_VLT.createExtIndex picks it when !dpn.isDictEncoded(),
+ * indexr-vlt-segment/.../VersionAdapter_VLT.java:167-181).  It reads every row of the decoded pack: INT compares
+ * (int) numValue, LONG numValue, FLOAT (float) Double.longBitsToDouble(numValue), DOUBLE Double.longBitsToDouble(numValue)
+ * with the language's ==, >, >=, <= (a NaN never matches, -0.0 equals 0.0); strings compare as unsigned bytes, then by
+ * length (BytesUtil.compareBytes); LIKE is SQLLike.match on each row and rejects numeric packs
+ * (IXR_ERR_UNSUPPORTED_TYPE).  Works on any decoded pack, dictionary encoded or not: the input is a decoded-pack arena
+ * as ixr_plan_run leaves it (src_off = the pack's out_off).  Keys, bitmaps and the return value are as in
+ * ixr_plan_run_filter; results[i] is IXR_BITMAP_NONE or IXR_BITMAP_SOME (never ALL: fixBitmapInPack,
+ * PackExtIndex.java:32-39), IXR_ERR_DATA_CORRUPTED for string offsets that leave the pack, IXR_ERR_INVALID_ARGUMENT for a
+ * data_size too small for obj_count rows.  The call synchronises with `stream`.
+ */
+typedef struct ixr_scan_filter_desc {
+    uint64_t src_off;    /* decoded pack inside the decoded arena, multiple of 8 */
+    uint64_t values_off; /* where this pack's keys start in `values`, multiple of 8 */
+    int32_t  data_type;  /* IXR_INT ... IXR_STRING */
+    int32_t  obj_count;  /* rows in the pack */
+    int32_t  data_size;  /* dpn.dataSize of the pack */
+    int32_t  op;         /* IXR_FILTER_* */
+    int32_t  n_values;   /* as in ixr_filter_desc */
+    int32_t  reserved;
+} ixr_scan_filter_desc;
+int32_t ixr_scan_filter_run(int32_t device, const ixr_scan_filter_desc* descs, int32_t n, const void* d_decoded,
+                            uint64_t decoded_bytes, const void* values, uint64_t values_bytes, void* d_bitmaps,
+                            uint64_t bitmap_bytes, int32_t* results, void* stream);
+
 /* ---- engine hand-back on device -----------------------------------------------------------------------------------
  * The step right after the decode in the Spark reader: decoded pack -> column vector contents for rows
  * [row_offset, row_offset + row_count), DefaultPackReader.readByCopy / readBySet

@@ -860,3 +860,66 @@ extern "C" int32_t ixr_plan_run_filter(ixr_plan* pl, const void* d_in, uint64_t 
     }
     return bad;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// predicates on the rows of decoded packs (ExtIndex_SimpleBits.java:25-331)
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int32_t ixr_scan_filter_run(int32_t device, const ixr_scan_filter_desc* descs, int32_t n, const void* d_decoded,
+                                       uint64_t decoded_bytes, const void* values, uint64_t values_bytes, void* d_bitmaps,
+                                       uint64_t bitmap_bytes, int32_t* results, void* stream) {
+    if (n < 0 || (n > 0 && (!descs || !d_decoded || !values || !d_bitmaps || !results))) return fail(IXR_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return 0;
+    if ((uintptr_t)d_bitmaps & 7) return fail(IXR_ERR_INVALID_ARGUMENT, "misaligned bitmap pointer");
+    if (bitmap_bytes < (uint64_t)n * IXR_BITMAP_BYTES) return fail(IXR_ERR_INVALID_ARGUMENT, "bitmap area too small: %d packs need %llu bytes", n, (unsigned long long)n * IXR_BITMAP_BYTES);
+    int32_t rc = ixr_init(device);
+    if (rc) return rc;
+    // host-side checks of what the kernel will index with: the decoded pack inside the arena, the keys inside the value buffer
+    std::vector<ScanFilterDesc> hd((size_t)n);
+    for (int i = 0; i < n; i++) {
+        const ixr_scan_filter_desc& f = descs[i];
+        if (f.data_type < IXR_INT || f.data_type > IXR_STRING || f.obj_count < 1 || f.obj_count > IXR_PACK_MAX_ROWS || f.data_size < 0)
+            return fail(IXR_ERR_INVALID_ARGUMENT, "scan filter %d: bad data type, row count or data size", i);
+        if ((f.src_off & 7) || f.src_off + (uint64_t)f.data_size > decoded_bytes) return fail(IXR_ERR_INVALID_ARGUMENT, "scan filter %d: pack outside the decoded arena", i);
+        if (f.op < IXR_FILTER_EQUAL || f.op > IXR_FILTER_LIKE || f.n_values < 1 || f.n_values > (1 << 20) || (f.values_off & 7) ||
+            (f.op == IXR_FILTER_BETWEEN && f.n_values < 2) || (f.op == IXR_FILTER_LIKE && f.n_values != 1))
+            return fail(IXR_ERR_INVALID_ARGUMENT, "scan filter %d: bad op, value count or offset", i);
+        const bool str_keys = f.data_type == IXR_STRING || f.op == IXR_FILTER_LIKE;
+        uint64_t need = str_keys ? 4ull * ((uint64_t)f.n_values + 1) : 8ull * (uint64_t)f.n_values;
+        if (f.values_off + need > values_bytes) return fail(IXR_ERR_INVALID_ARGUMENT, "scan filter %d: keys outside the value buffer", i);
+        if (str_keys) {
+            const int32_t* off = (const int32_t*)((const uint8_t*)values + f.values_off);
+            for (int v = 0; v < f.n_values; v++)
+                if (off[v] < 0 || off[v + 1] < off[v]) return fail(IXR_ERR_INVALID_ARGUMENT, "scan filter %d: key offsets not ascending", i);
+            need += (uint64_t)off[f.n_values];
+            if (f.values_off + need > values_bytes) return fail(IXR_ERR_INVALID_ARGUMENT, "scan filter %d: key bytes outside the value buffer", i);
+        }
+        ScanFilterDesc& d = hd[(size_t)i];
+        d.src_off = f.src_off; d.values_off = f.values_off; d.data_type = f.data_type; d.obj_count = f.obj_count;
+        d.data_size = f.data_size; d.op = f.op; d.n_values = f.n_values; d.reserved = 0;
+    }
+    HIP_TRY(hipSetDevice(device), return IXR_ERR_HIP);
+    hipStream_t st = (hipStream_t)stream;
+    ScanFilterDesc* dd = nullptr;
+    uint8_t* d_vals = nullptr;
+    int32_t* dr = nullptr;
+    if (hipMalloc((void**)&dd, sizeof(ScanFilterDesc) * (size_t)n) != hipSuccess || hipMalloc((void**)&d_vals, values_bytes + 16) != hipSuccess ||
+        hipMalloc((void**)&dr, sizeof(int32_t) * (size_t)n) != hipSuccess)
+        rc = fail(IXR_ERR_OUT_OF_MEMORY, "hipMalloc failed");
+    if (!rc && (hipMemcpyAsync(dd, hd.data(), sizeof(ScanFilterDesc) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipMemcpyAsync(d_vals, values, values_bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipMemsetAsync(dr, 0, sizeof(int32_t) * (size_t)n, st) != hipSuccess))
+        rc = fail(IXR_ERR_HIP, "H2D failed");
+    if (!rc) {
+        launch_scan_filter(st, dd, n, (const uint8_t*)d_decoded, d_vals, (unsigned long long*)d_bitmaps, dr);
+        if (hipGetLastError() != hipSuccess) rc = fail(IXR_ERR_HIP, "kernel launch failed");
+    }
+    if (!rc && hipMemcpyAsync(results, dr, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st) != hipSuccess) rc = fail(IXR_ERR_HIP, "D2H failed");
+    if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = fail(IXR_ERR_HIP, "stream synchronise failed");
+    if (dd) (void)hipFree(dd);
+    if (d_vals) (void)hipFree(d_vals);
+    if (dr) (void)hipFree(dr);
+    if (rc) return rc;
+    int bad = 0;
+    for (int i = 0; i < n; i++) bad += results[i] < 0;
+    return bad;
+}

@@ -21,6 +21,7 @@
 //   string packs k_str_dict_scan -> k_front_decode -> k_str_index -> k_str_copy  (see each kernel)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "ixr_device.h"
 #include "ixr_launch.h"
@@ -1950,6 +1951,101 @@ __global__ __launch_bounds__(256) void k_filter_rows(const DevPack* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// k_scan_filter: predicates on the rows of a decoded pack (ExtIndex_SimpleBits.java:25-331, what packs without a
+// dictionary get).  One wave per 1024-row tile, one row per lane and round, 64 rows ballot into one bitmap word; all 1024
+// words of a pack are written.  results[d] must be 0 on entry: it becomes 2 when any row matches (fixBitmapInPack,
+// PackExtIndex.java:32-39: an empty bitmap is NONE, the rest comes back as it is) or a negative error.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int compare_bytes(const uint8_t* a, int alen, const uint8_t* b, int blen) {  // BytesUtil.compareBytes :7-19
+    const int len = min(alen, blen);
+    for (int i = 0; i < len; i++) {
+        const int c = (int)a[i] - (int)b[i];
+        if (c) return c;
+    }
+    return alen - blen;
+}
+template <typename T> __device__ __forceinline__ T scan_key(int64_t num) {
+    if constexpr (sizeof(T) == 4 && !std::is_floating_point<T>::value) return (T)(uint32_t)(uint64_t)num;  // (int) numValue
+    else if constexpr (!std::is_floating_point<T>::value) return (T)num;
+    else return (T)__longlong_as_double(num);  // (float) Double.longBitsToDouble(numValue) / Double.longBitsToDouble(numValue)
+}
+template <typename T> __device__ __forceinline__ bool scan_num(T v, int op, int nv, const int64_t* keys, T k0, T k1) {
+    switch (op) {
+        case 1: return v == k0;
+        case 2: { bool hit = false; for (int i = 0; i < nv && !hit; i++) hit = v == scan_key<T>(keys[i]); return hit; }
+        case 3: return v > k0;
+        case 4: return v > k0 || v == k0;
+        default: return v >= k0 && v <= k1;
+    }
+}
+__global__ __launch_bounds__(256) void k_scan_filter(const ScanFilterDesc* __restrict__ descs, const uint8_t* __restrict__ decoded,
+                                                     const uint8_t* __restrict__ values, unsigned long long* __restrict__ bitmaps,
+                                                     int32_t* __restrict__ results) {
+    const ScanFilterDesc D = descs[blockIdx.y];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n = (uint32_t)D.obj_count, tile = blockIdx.x * 4 + wave, tile_start = tile * 1024u;
+    unsigned long long* words = bitmaps + (size_t)blockIdx.y * 1024 + tile * 16;
+    const uint8_t* src = decoded + D.src_off;
+    const uint8_t* vals = values + D.values_off;
+    const int op = D.op, nv = D.n_values, dt = D.data_type;
+    int err = 0;
+    if (op == 6 && dt != 5) err = E_UNSUPPORTED_TYPE;  // "column type ... is illegal in LIKE"
+    else if (dt == 5 ? 4ull * (n + 1) > (uint64_t)D.data_size : (uint64_t)n * ((dt == 1 || dt == 3) ? 4u : 8u) > (uint64_t)D.data_size) err = -1000;
+    unsigned long long mine = 0;
+    bool bad = false;
+    if (!err && tile_start < n) {
+        const int64_t* nk = (const int64_t*)vals;
+        const int32_t* koff = (const int32_t*)vals;
+        const uint8_t* kbody = vals + 4ull * ((uint32_t)nv + 1);
+        const int32_t* off = (const int32_t*)src;
+        const uint8_t* body = src + 4ull * (n + 1);
+        const int64_t body_cap = (int64_t)D.data_size - 4ll * (n + 1);
+#pragma unroll 1
+        for (int q = 0; q < 16; q++) {
+            const uint32_t r = tile_start + q * 64 + lane;
+            bool hit = false;
+            if (r < n) {
+                switch (dt) {
+                    case 1: hit = scan_num<int32_t>(((const int32_t*)src)[r], op, nv, nk, scan_key<int32_t>(nk[0]), scan_key<int32_t>(nk[nv > 1])); break;
+                    case 2: hit = scan_num<int64_t>(((const int64_t*)src)[r], op, nv, nk, scan_key<int64_t>(nk[0]), scan_key<int64_t>(nk[nv > 1])); break;
+                    case 3: hit = scan_num<float>(((const float*)src)[r], op, nv, nk, scan_key<float>(nk[0]), scan_key<float>(nk[nv > 1])); break;
+                    case 4: hit = scan_num<double>(((const double*)src)[r], op, nv, nk, scan_key<double>(nk[0]), scan_key<double>(nk[nv > 1])); break;
+                    default: {
+                        const int32_t a = off[r], b = off[r + 1];
+                        if (a < 0 || b < a || (int64_t)b > body_cap) { bad = true; break; }
+                        const uint8_t* sp = body + a;
+                        const int sl = b - a;
+                        if (op == 1 || op == 2) {  // equal :72-84, in :146-161: same length and same bytes
+                            for (int i = 0; i < nv && !hit; i++) {
+                                const int kl = koff[i + 1] - koff[i];
+                                hit = kl == sl && compare_bytes(sp, sl, kbody + koff[i], kl) == 0;
+                            }
+                        } else if (op == 3 || op == 4) {  // greater :215-229
+                            const int c = compare_bytes(sp, sl, kbody + koff[0], koff[1] - koff[0]);
+                            hit = c > 0 || (op == 4 && c == 0);
+                        } else if (op == 5) {  // between :287-306
+                            hit = compare_bytes(sp, sl, kbody + koff[0], koff[1] - koff[0]) >= 0 &&
+                                  compare_bytes(sp, sl, kbody + koff[1], koff[2] - koff[1]) <= 0;
+                        } else {  // like :314-331
+                            hit = like_match(sp, sl, kbody + koff[0], koff[1] - koff[0]);
+                        }
+                    }
+                }
+            }
+            const unsigned long long word = __ballot(hit);
+            if (lane == q) mine = word;
+        }
+    }
+    if (lane < 16) words[lane] = mine;
+    const unsigned long long anyhit = __ballot(mine != 0), anybad = __ballot(bad);
+    if (lane == 0) {
+        if (err) { if (tile == 0) results[blockIdx.y] = err; }
+        else if (anybad) atomicMin(&results[blockIdx.y], E_CORRUPT);
+        else if (anyhit) atomicCAS(&results[blockIdx.y], 0, 2);  // leaves an error another tile reported
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // k_handback: decoded pack -> Spark column vector contents (DefaultPackReader.readByCopy / readBySet,
 // DefaultPackReader.java:164-241).  grid = (blocks per descriptor, descriptors); elementwise, memory bound.
 // ---------------------------------------------------------------------------------------------------------------
@@ -2144,6 +2240,11 @@ void launch_filter_rows(const LaunchCtx& c, const int* list, int count, DevFilte
     if (count <= 0) return;
     hipLaunchKernelGGL(k_filter_rows, dim3(IXR_PACK_TILES / 4, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, filters,
                        matches, bitmaps, c.scratch);
+}
+void launch_scan_filter(hipStream_t stream, const ScanFilterDesc* descs, int count, const uint8_t* decoded, const uint8_t* values,
+                        unsigned long long* bitmaps, int32_t* results) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_scan_filter, dim3(IXR_PACK_TILES / 4, count), dim3(256), 0, stream, descs, decoded, values, bitmaps, results);
 }
 void launch_handback(hipStream_t stream, const HandbackDesc* descs, int count, const uint8_t* decoded, uint8_t* out, int32_t* status) {
     if (count <= 0) return;

@@ -42,7 +42,7 @@ void launch_dict_struct(const LaunchCtx& c, const int* list, int count);
 struct DevFilter {
     int32_t op, n_values;
     uint64_t values_off;  // into the device copy of the key buffer
-    uint32_t match_off;   // into the matched-id array (one slot per key)
+    uint32_t match_off;   // into the matched-id array (one slot per key; LIKE: one per row of the pack)
     int32_t result;       // out: 0 none, 1 all, 2 bitmap, < 0 error
     uint32_t from, to;    // out: id range [from, to) for the range predicates
     uint32_t n_match;     // out: number of matched ids (EQUAL, IN)
@@ -52,6 +52,14 @@ void launch_filter_search(const LaunchCtx& c, const int* list, int count, DevFil
 void launch_filter_like(const LaunchCtx& c, const int* list, int count, DevFilter* filters, const uint8_t* values, uint32_t* matches);
 void launch_filter_rows(const LaunchCtx& c, const int* list, int count, DevFilter* filters, const uint32_t* matches,
                         unsigned long long* bitmaps);
+
+// predicates on the rows of decoded packs (ExtIndex_SimpleBits); descs / results are device arrays, results zeroed by the caller
+struct ScanFilterDesc {
+    uint64_t src_off, values_off;
+    int32_t data_type, obj_count, data_size, op, n_values, reserved;
+};
+void launch_scan_filter(hipStream_t stream, const ScanFilterDesc* descs, int count, const uint8_t* decoded, const uint8_t* values,
+                        unsigned long long* bitmaps, int32_t* results);
 
 // engine hand-back (decoded pack -> column vector contents); descs / status are device arrays
 struct HandbackDesc {

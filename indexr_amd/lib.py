@@ -60,6 +60,12 @@ BITMAP_NONE, BITMAP_ALL, BITMAP_SOME = 0, 1, 2
 BITMAP_BYTES = 8192
 
 
+class ScanFilterDesc(C.Structure):
+    """ixr_scan_filter_desc: a predicate on the rows of one decoded pack (ExtIndex_SimpleBits.java)"""
+    _fields_ = [("src_off", C.c_uint64), ("values_off", C.c_uint64), ("data_type", C.c_int32), ("obj_count", C.c_int32),
+                ("data_size", C.c_int32), ("op", C.c_int32), ("n_values", C.c_int32), ("reserved", C.c_int32)]
+
+
 class SynthReq(C.Structure):
     _fields_ = [("kind", C.c_int32), ("pack_id", C.c_uint32), ("rows", C.c_int32), ("is_indexed", C.c_int32)]
 
@@ -97,6 +103,7 @@ _sig = {
     "ixr_compress_pack": (_i32, [_i32, _i32, _i32, _vp, _i32, _vp, _i32, C.POINTER(_i32)]),
     "ixr_compress_bound": (_i32, [_i32, _i32]),
     "ixr_plan_run_filter": (_i32, [_vp, _vp, _u64, C.POINTER(FilterDesc), _vp, _u64, _vp, _u64, C.POINTER(_i32), _vp]),
+    "ixr_scan_filter_run": (_i32, [_i32, C.POINTER(ScanFilterDesc), _i32, _vp, _u64, _vp, _u64, _vp, _u64, C.POINTER(_i32), _vp]),
     "ixr_handback_bound": (_u64, [C.POINTER(HandbackDesc)]),
     "ixr_handback_run": (_i32, [_i32, C.POINTER(HandbackDesc), _i32, _vp, _u64, _vp, _u64, C.POINTER(_i32), _vp]),
     "ixr_synth_data_type": (_i32, [_i32]),
@@ -304,6 +311,18 @@ def handback_run(descs, d_decoded, decoded_bytes, d_out, out_bytes, device=0, st
     if bad < 0:
         raise IxrError(bad, "ixr_handback_run")
     return np.frombuffer(st, dtype=np.int32).copy(), bad
+
+
+def scan_filter_run(descs, d_decoded, decoded_bytes, values, d_bitmaps, bitmap_bytes, device=0, stream=None):
+    """ixr_scan_filter_run: -> (results per pack, number of packs with a negative result)"""
+    n = len(descs)
+    arr = (ScanFilterDesc * n)(*descs)
+    res = (_i32 * n)()
+    values = np.ascontiguousarray(values, dtype=np.uint8)
+    bad = lib.ixr_scan_filter_run(device, arr, n, d_decoded, decoded_bytes, _ptr(values), len(values), d_bitmaps, bitmap_bytes, res, stream)
+    if bad < 0:
+        raise IxrError(bad, "ixr_scan_filter_run")
+    return np.frombuffer(res, dtype=np.int32).copy(), bad
 
 
 def filter_keys(keys_per_pack, is_string_per_pack):

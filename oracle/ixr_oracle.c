@@ -1278,3 +1278,78 @@ int ixo_filter(int data_type, int encode_type, int n, const uint8_t* pack, int p
     free(ds);
     return result;
 }
+
+static double bits_to_double(int64_t bits) { double d; memcpy(&d, &bits, 8); return d; }  /* Double.longBitsToDouble */
+
+/* ExtIndex_SimpleBits (indexr-segment/src/main/java/io/indexr/segment/index/ExtIndex_SimpleBits.java): equal :25-89, in
+ * :91-166, greater :168-234, between :236-311, like :313-331, row after row over the decoded pack.  Keys as in
+ * ixo_filter.  Returns 0 (NONE: fixBitmapInPack on an empty bitmap) or 2, -102 for LIKE on numbers. */
+int ixo_scan_filter(int data_type, int n, const uint8_t* data, int data_size, int op, int n_values,
+                    const int64_t* num_values, const uint8_t* str_values, uint64_t* bitmap) {
+    memset(bitmap, 0, 8192);
+    if (op < 1 || op > 6 || n_values < 1 || (op == 5 && n_values < 2)) return -1000;
+    if (op == 6 && data_type != IXO_STRING) return -102;
+    if (data_type == IXO_STRING ? 4 * ((int64_t)n + 1) > data_size : (int64_t)n * ((data_type == IXO_INT || data_type == IXO_FLOAT) ? 4 : 8) > data_size) return -1000;
+    int any = 0;
+#define SET(i) do { bitmap[(i) >> 6] |= 1ull << ((i) & 63); any = 1; } while (0)
+#define SCAN(T, LOAD, KEYOF)                                                                                             \
+    do {                                                                                                                 \
+        const T k0 = KEYOF(num_values[0]);                                                                               \
+        const T k1 = KEYOF(num_values[n_values > 1]);                                                                    \
+        for (int i = 0; i < n; i++) {                                                                                    \
+            T v; memcpy(&v, data + (size_t)i * sizeof(T), sizeof(T));                                                    \
+            int hit = 0;                                                                                                 \
+            if (op == 1) hit = v == k0;                                                                                  \
+            else if (op == 2) { for (int e = 0; e < n_values && !hit; e++) hit = v == KEYOF(num_values[e]); }            \
+            else if (op == 3) hit = v > k0;                                                                              \
+            else if (op == 4) hit = v > k0 || v == k0;                                                                   \
+            else hit = v >= k0 && v <= k1;                                                                               \
+            if (hit) SET(i);                                                                                             \
+        }                                                                                                                \
+    } while (0)
+#define K_INT(x) ((int32_t)(uint32_t)(uint64_t)(x))
+#define K_LONG(x) ((int64_t)(x))
+#define K_FLOAT(x) ((float)bits_to_double(x))
+#define K_DOUBLE(x) (bits_to_double(x))
+    switch (data_type) {
+        case IXO_INT: SCAN(int32_t, 0, K_INT); break;
+        case IXO_LONG: SCAN(int64_t, 0, K_LONG); break;
+        case IXO_FLOAT: SCAN(float, 0, K_FLOAT); break;
+        case IXO_DOUBLE: SCAN(double, 0, K_DOUBLE); break;
+        case IXO_STRING: {
+            const uint8_t* body = data + 4 * ((size_t)n + 1);
+            const uint8_t* kbody = str_values + 4 * ((size_t)n_values + 1);
+            for (int i = 0; i < n; i++) {
+                const int32_t a = ld32(data + 4 * (size_t)i), b = ld32(data + 4 * (size_t)(i + 1));
+                if (a < 0 || b < a || 4 * ((int64_t)n + 1) + b > data_size) return IXO_DATA_CORRUPTED;
+                const uint8_t* sp = body + a;
+                const int sl = b - a;
+                int hit = 0;
+                if (op == 1 || op == 2) {
+                    for (int e = 0; e < n_values && !hit; e++) {
+                        const int32_t ka = ld32(str_values + 4 * (size_t)e), kb = ld32(str_values + 4 * (size_t)(e + 1));
+                        hit = kb - ka == sl && memcmp(sp, kbody + ka, (size_t)sl) == 0;
+                    }
+                } else if (op == 6) {
+                    const int32_t ka = ld32(str_values), kb = ld32(str_values + 4);
+                    hit = like_match(sp, sl, kbody + ka, kb - ka, 0, 0);
+                } else {
+                    const int32_t ka = ld32(str_values), kb = ld32(str_values + 4);
+                    const int c1 = compare_bytes(sp, sl, kbody + ka, kb - ka);
+                    if (op == 3) hit = c1 > 0;
+                    else if (op == 4) hit = c1 >= 0;
+                    else {
+                        const int32_t kc = ld32(str_values + 8);
+                        hit = c1 >= 0 && compare_bytes(sp, sl, kbody + kb, kc - kb) <= 0;
+                    }
+                }
+                if (hit) SET(i);
+            }
+            break;
+        }
+        default: return -102;
+    }
+#undef SCAN
+#undef SET
+    return any ? 2 : 0;
+}

@@ -101,6 +101,12 @@ int ixo_like(const uint8_t* str, int str_len, const uint8_t* pattern, int patter
 int ixo_filter(int data_type, int encode_type, int n, const uint8_t* pack, int pack_size, int op, int n_values,
                const int64_t* num_values, const uint8_t* str_values, uint64_t* bitmap);
 
+/* ExtIndex_SimpleBits (indexr-segment/.../segment/index/ExtIndex_SimpleBits.java:25-331): the same predicates evaluated on
+ * every row of a decoded pack (`data`, data_size bytes); keys as in ixo_filter.  Returns 0 (NONE) or 2 (bitmap), -102
+ * for LIKE on a numeric pack, IXO_DATA_CORRUPTED for string offsets that leave the pack. */
+int ixo_scan_filter(int data_type, int n, const uint8_t* data, int data_size, int op, int n_values,
+                    const int64_t* num_values, const uint8_t* str_values, uint64_t* bitmap);
+
 #ifdef __cplusplus
 }
 #endif

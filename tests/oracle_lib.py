@@ -58,6 +58,8 @@ for name, res, args in [
     ("ixo_decompress_pack", C.c_int, [C.c_int, C.c_int, C.c_int, _u8p, C.c_int, _u8p, C.c_int]),
     ("ixo_get_dict_struct", C.c_int, [C.c_int, C.c_int, _u8p, C.c_int, _u8p, C.c_int]),
     ("ixo_filter", C.c_int, [C.c_int, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), _u8p, C.POINTER(C.c_uint64)]),
+    ("ixo_scan_filter", C.c_int, [C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), _u8p, C.POINTER(C.c_uint64)]),
+    ("ixo_like", C.c_int, [_u8p, C.c_int, _u8p, C.c_int]),
     ("ixo_handback", C.c_int, [C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]),
 ]:
     fn = getattr(lib, name)
@@ -160,4 +162,18 @@ def filter_pack(pack, data_type, encode_type, n, op, keys):
         nv = np.asarray(keys, dtype=np.int64)
         r = lib.ixo_filter(data_type, encode_type, n, _p(pack), len(pack), op, len(keys), nv.ctypes.data_as(C.POINTER(C.c_int64)),
                            None, bitmap.ctypes.data_as(C.POINTER(C.c_uint64)))
+    return r, bitmap
+
+
+def scan_filter_pack(data, data_type, n, op, keys):
+    """ExtIndex_SimpleBits on one decoded pack -> (0 / 2 or error, bitmap np.uint64[1024]).  keys: ints (numValue) or bytes."""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    bitmap = np.zeros(1024, dtype=np.uint64)
+    bp = bitmap.ctypes.data_as(C.POINTER(C.c_uint64))
+    if keys and isinstance(keys[0], (bytes, bytearray)):
+        sv = rows_to_bytes(list(keys), STRING)
+        r = lib.ixo_scan_filter(data_type, n, _p(data), len(data), op, len(keys), None, _p(sv), bp)
+    else:
+        nv = np.asarray(keys, dtype=np.int64)
+        r = lib.ixo_scan_filter(data_type, n, _p(data), len(data), op, len(keys), nv.ctypes.data_as(C.POINTER(C.c_int64)), None, bp)
     return r, bitmap

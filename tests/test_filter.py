@@ -1,7 +1,6 @@
 """Predicate evaluation on dictionary ids (ExtIndex_DictBits.java:33-200).
 CPU: the oracle against a direct numpy statement of "which rows satisfy the predicate" (for keys where dictionary search
 and value comparison agree: no NaN / -0.0 keys).  GPU: the device path against the oracle, bit for bit, for every op."""
-import ctypes as C
 import re
 import struct
 
@@ -98,8 +97,7 @@ def like_regex(pattern):
 
 
 def oracle_like(s, p):
-    O.lib.ixo_like.restype = C.c_int
-    return bool(O.lib.ixo_like(C.c_char_p(s), len(s), C.c_char_p(p), len(p)))
+    return bool(O.lib.ixo_like(O._p(s), len(s), O._p(p), len(p)))
 
 
 LIKE_PATTERNS = [b"www.s1%", b"%/25_", b"%", b"%%", b"nomatch%", b"www.s_.com/%", b"%s2%.com%7", b"www.s0.com/0", b"", b"_",
