@@ -43,6 +43,9 @@ static int32_t fail(int32_t code, const char* fmt, ...) {
     } while (0)
 
 extern "C" const char* ixr_last_error(void) { return g_err; }
+namespace ixr {
+int32_t set_error(int32_t code, const char* message) { return fail(code, "%s", message); }
+}
 
 extern "C" int32_t ixr_device_count(void) {
     int n = 0;

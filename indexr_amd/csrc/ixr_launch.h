@@ -20,6 +20,9 @@ struct LaunchCtx {
     int dict_only = 0;     // 1: build dictionaries only; packs whose decode writes straight to the output arena are skipped
 };
 
+// records the calling thread's last error (what ixr_last_error returns) and hands `code` back
+int32_t set_error(int32_t code, const char* message);
+
 // `list` is a device array of `count` pack indices.
 void launch_parse(const LaunchCtx& c, const int* list, int count);
 void launch_delta(const LaunchCtx& c, const int* list, int count, int width, int streams);

@@ -66,6 +66,12 @@ class ScanFilterDesc(C.Structure):
                 ("data_size", C.c_int32), ("op", C.c_int32), ("n_values", C.c_int32), ("reserved", C.c_int32)]
 
 
+class EncodeDesc(C.Structure):
+    """ixr_encode_desc: one decoded numeric pack to compress on the device (PackCompressor_VLT.compress)"""
+    _fields_ = [("src_off", C.c_uint64), ("dst_off", C.c_uint64), ("data_type", C.c_int32), ("is_indexed", C.c_int32),
+                ("obj_count", C.c_int32), ("data_size", C.c_int32), ("pack_size", C.c_int32), ("encode_type", C.c_int32)]
+
+
 class SynthReq(C.Structure):
     _fields_ = [("kind", C.c_int32), ("pack_id", C.c_uint32), ("rows", C.c_int32), ("is_indexed", C.c_int32)]
 
@@ -104,6 +110,7 @@ _sig = {
     "ixr_compress_bound": (_i32, [_i32, _i32]),
     "ixr_plan_run_filter": (_i32, [_vp, _vp, _u64, C.POINTER(FilterDesc), _vp, _u64, _vp, _u64, C.POINTER(_i32), _vp]),
     "ixr_scan_filter_run": (_i32, [_i32, C.POINTER(ScanFilterDesc), _i32, _vp, _u64, _vp, _u64, _vp, _u64, C.POINTER(_i32), _vp]),
+    "ixr_encode_run": (_i32, [_i32, C.POINTER(EncodeDesc), _i32, _vp, _u64, _vp, _u64, _u64, _vp]),
     "ixr_handback_bound": (_u64, [C.POINTER(HandbackDesc)]),
     "ixr_handback_run": (_i32, [_i32, C.POINTER(HandbackDesc), _i32, _vp, _u64, _vp, _u64, C.POINTER(_i32), _vp]),
     "ixr_synth_data_type": (_i32, [_i32]),
@@ -323,6 +330,16 @@ def scan_filter_run(descs, d_decoded, decoded_bytes, values, d_bitmaps, bitmap_b
     if bad < 0:
         raise IxrError(bad, "ixr_scan_filter_run")
     return np.frombuffer(res, dtype=np.int32).copy(), bad
+
+
+def encode_run(descs, d_data, data_bytes, d_out, out_bytes, device=0, scratch_budget=0, stream=None):
+    """ixr_encode_run: fills pack_size / encode_type of every descriptor -> (ctypes array of descriptors, failed packs)"""
+    n = len(descs)
+    arr = descs if isinstance(descs, C.Array) else (EncodeDesc * n)(*descs)
+    bad = lib.ixr_encode_run(device, arr, n, d_data, data_bytes, d_out, out_bytes, scratch_budget, stream)
+    if bad < 0:
+        raise IxrError(bad, "ixr_encode_run")
+    return arr, bad
 
 
 def filter_keys(keys_per_pack, is_string_per_pack):

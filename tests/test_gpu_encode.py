@@ -1,0 +1,145 @@
+"""The numeric pack encoder on the device (PackCompressor_VLT.compress :23-96 as a batch) against the CPU oracle's encoder:
+the same codec choice and the same bytes, pack for pack."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from indexr_amd import lib as L
+
+
+def columns(n, rng):
+    """(name, data type, is_indexed, rows) covering both codecs, plain and DELTA-coded dictionaries, runs, bit widths 0..64"""
+    runs = np.repeat(rng.integers(0, 16, n // 4 + 8), rng.geometric(1 / 32, n // 4 + 8))[:n]
+    if len(runs) < n:
+        runs = np.resize(runs, n)
+    short_runs = np.repeat(rng.integers(0, 5, n), rng.integers(1, 12, n))[:n]
+    out = [
+        ("i_seq", O.INT, False, (np.cumsum(rng.integers(0, 4, n)) - 1000).astype("<i4")),
+        ("i_rand", O.INT, False, rng.integers(-2**31, 2**31, n).astype("<i4")),
+        ("i_rand_idx", O.INT, True, rng.integers(-2**31, 2**31, n).astype("<i4")),
+        ("i_cat", O.INT, False, rng.integers(0, 1000, n).astype("<i4") * 37 - 5000),
+        ("i_runs", O.INT, False, runs.astype("<i4")),
+        ("i_short_runs", O.INT, True, short_runs.astype("<i4")),
+        ("i_const", O.INT, False, np.full(n, -7, dtype="<i4")),
+        ("i_two", O.INT, True, (np.arange(n) // 9 % 2).astype("<i4")),
+        ("i_extremes", O.INT, False, rng.choice(np.array([-2**31, 2**31 - 1, 0, -1, 1], dtype="<i4"), n)),
+        ("l_ts", O.LONG, False, (np.cumsum(rng.integers(0, 2000, n)) + 1_500_000_000_000).astype("<i8")),
+        ("l_card", O.LONG, False, rng.choice(rng.integers(0, 2**40, 4096), n).astype("<i8")),
+        ("l_rand", O.LONG, True, rng.integers(-2**63, 2**63, n, dtype=np.int64).astype("<i8")),
+        ("l_const", O.LONG, False, np.full(n, 2**62, dtype="<i8")),
+        ("l_extremes", O.LONG, False, rng.choice(np.array([-2**63, 2**63 - 1, 0, -1], dtype="<i8"), n)),
+        ("f_card", O.FLOAT, False, (rng.integers(0, 10000, n) / 10).astype("<f4")),
+        ("f_rand", O.FLOAT, True, rng.standard_normal(n).astype("<f4")),
+        ("d_card", O.DOUBLE, False, (rng.integers(0, 50000, n) / 10).astype("<f8")),
+        ("d_rand", O.DOUBLE, False, rng.standard_normal(n).astype("<f8")),
+    ]
+    return out
+
+
+def special_columns():
+    nan2 = np.array([0x7fc00001], dtype="<u4").view("<f4")[0]
+    f = np.array([0.0, -0.0, 1.5, np.nan, np.inf, -np.inf, 2.5, 1.5, -0.0, nan2, 0.0] * 13, dtype="<f4")
+    f[3] = nan2  # the first NaN the pack holds carries a payload
+    dn = np.array([0x7ff8000000000123], dtype="<u8").view("<f8")[0]
+    d = np.array([0.0, -0.0, 1.5, dn, np.inf, -np.inf, np.nan, 2.5, -0.0, 5e-324, 1e308] * 9, dtype="<f8")
+    return [("f_special", O.FLOAT, False, f), ("d_special", O.DOUBLE, True, d),
+            ("f_nan_only", O.FLOAT, False, np.full(70, np.nan, dtype="<f4")),
+            ("f_zeros", O.FLOAT, False, np.array([-0.0, 0.0] * 40, dtype="<f4"))]
+
+
+def build_cases():
+    rng = np.random.default_rng(2024)
+    cases = []
+    for n in (65536, 12345):
+        cases += columns(n, rng)
+    for n in (1, 2, 7, 8, 9, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 257, 1023, 1025):
+        cases.append(("i_small%d" % n, O.INT, False, rng.integers(0, 3, n).astype("<i4")))
+        cases.append(("i_wide%d" % n, O.INT, False, rng.integers(-2**31, 2**31, n).astype("<i4")))
+        cases.append(("l_small%d" % n, O.LONG, True, (rng.integers(0, 100, n) * 10**12).astype("<i8")))
+        cases.append(("d_small%d" % n, O.DOUBLE, False, rng.integers(0, 80, n).astype("<f8") / 4))
+    cases += special_columns()
+    # a long run at the very end (stays bit packed), a run of exactly 8, runs of 7
+    tail = np.concatenate([np.arange(40), np.full(100, 3)]).astype("<i4")
+    eight = np.concatenate([np.full(8, 1), np.full(8, 2), np.full(7, 1), np.full(9, 0), [5]]).astype("<i4")
+    cases += [("i_tail_run", O.INT, True, tail), ("i_eight", O.INT, True, eight)]
+    return cases
+
+
+def test_oracle_encoder_round_trips_the_test_columns():
+    """the packs the GPU encoder is compared with decode back to their rows (bit patterns; float specials excepted)"""
+    for name, dt, idx, rows in build_cases()[:40]:
+        data = O.rows_to_bytes(rows, dt)
+        pack, et = O.compress_pack(data, dt, len(rows), idx)
+        back, consumed = O.decompress_pack(pack, dt, et, len(rows), len(data))
+        assert consumed == len(pack) and np.array_equal(back, data), name
+
+
+@pytest.mark.gpu
+def test_gpu_encoder_writes_the_bytes_of_the_reference_encoder():
+    cases = build_cases()
+    descs, parts, src, dst = [], [], 0, 0
+    for name, dt, idx, rows in cases:
+        data = O.rows_to_bytes(rows, dt)
+        parts.append(data)
+        pad = -len(data) % 16
+        parts.append(np.zeros(pad, dtype=np.uint8))
+        cap = L.lib.ixr_compress_bound(len(rows), len(data))
+        descs.append(L.EncodeDesc(src, dst, dt, int(idx), len(rows), len(data), 0, 0))
+        src += len(data) + pad
+        dst += (cap + 15) & ~15
+    arena = np.concatenate(parts)
+    d_data, d_out = L.DeviceBuffer(0, len(arena)), L.DeviceBuffer(0, dst)
+    try:
+        d_data.upload(arena)
+        d_out.upload(np.full(dst, 0xCD, dtype=np.uint8))
+        for budget in (0, 24 << 20):  # one group; several groups
+            arr, bad = L.encode_run(descs, d_data.ptr, len(arena), d_out.ptr, dst, scratch_budget=budget)
+            assert bad == 0, [(c[0], a.pack_size) for c, a in zip(cases, arr) if a.pack_size < 0]
+            host = d_out.download()
+            types = set()
+            for (name, dt, idx, rows), a in zip(cases, arr):
+                want, et = O.compress_pack(O.rows_to_bytes(rows, dt), dt, len(rows), idx)
+                assert a.encode_type == et, (name, a.encode_type, et)
+                assert a.pack_size == len(want), (name, a.pack_size, len(want))
+                got = host[a.dst_off:a.dst_off + a.pack_size]
+                assert np.array_equal(got, want), (name, int(np.argmax(got != want)))
+                cap = L.lib.ixr_compress_bound(len(rows), len(rows) * (4 if dt in (O.INT, O.FLOAT) else 8))
+                assert (host[a.dst_off + a.pack_size:a.dst_off + cap] == 0xCD).all(), name  # nothing written past the pack
+                types.add(et)
+            assert types == {O.DELTA, O.DICT_COMPRESS}
+            d_out.upload(np.full(dst, 0xCD, dtype=np.uint8))
+    finally:
+        d_data.free()
+        d_out.free()
+
+
+@pytest.mark.gpu
+def test_gpu_encoder_output_decodes_on_the_gpu():
+    """encode -> decode round trip on the device: the decoder gets the packs where the encoder left them"""
+    rng = np.random.default_rng(7)
+    cols = columns(65536, rng)
+    descs, parts, src, dst = [], [], 0, 0
+    for name, dt, idx, rows in cols:
+        data = O.rows_to_bytes(rows, dt)
+        parts.append(data)
+        cap = L.lib.ixr_compress_bound(len(rows), len(data))
+        descs.append(L.EncodeDesc(src, dst, dt, int(idx), len(rows), len(data), 0, 0))
+        src += len(data)
+        dst += (cap + 15) & ~15
+    arena = np.concatenate(parts)
+    d_data, d_cmp, d_back = L.DeviceBuffer(0, len(arena)), L.DeviceBuffer(0, dst + L.IN_SLACK), L.DeviceBuffer(0, len(arena) + 16)
+    plan = None
+    try:
+        d_data.upload(arena)
+        arr, bad = L.encode_run(descs, d_data.ptr, len(arena), d_cmp.ptr, dst)
+        assert bad == 0
+        pdescs = [L.PackDesc(a.dst_off, a.src_off, a.pack_size, a.data_size, a.obj_count, a.encode_type, a.data_type, 0) for a in arr]
+        plan = L.Plan(0, pdescs)
+        plan.run(d_cmp.ptr, dst + L.IN_SLACK, d_back.ptr, len(arena) + 16)
+        status, nbad = plan.status()
+        assert nbad == 0, status
+        assert np.array_equal(d_back.download()[:len(arena)], arena)
+    finally:
+        if plan is not None:
+            plan.destroy()
+        d_data.free(); d_cmp.free(); d_back.free()
