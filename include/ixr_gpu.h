@@ -258,7 +258,12 @@ int32_t ixr_compress_bound(int32_t obj_count, int32_t data_size);
  *   d_data      device arena holding the decoded packs (raw little-endian arrays), src_off multiple of 16
  *   d_out       device arena; every pack gets a slot of ixr_compress_bound(obj_count, data_size) bytes at dst_off
  *               (multiple of 16); the compressed pack starts at dst_off
- *   descs[i]    pack_size receives the compressed size or a negative error, encode_type the CodecType id
+ *   descs[i]    pack_size receives the compressed size or a negative error, encode_type the CodecType id; min_value,
+ *               max_value and sum receive what DataPackCreator_VLT.from (DataPackCreator_VLT.java:21-163) puts into the
+ *               DataPackNode: INT / LONG: min, max and the wrapping 64-bit sum; FLOAT / DOUBLE: the Math.min / Math.max
+ *               fold (-0.0 < 0.0; with NaNs in the pack both are the last NaN) as Double.doubleToRawLongBits of the
+ *               widened value, and the raw bits of the row-after-row sum in the column's precision, widened to double
+ *               (a NaN sum is some NaN: which payload survives an addition is the hardware's choice)
  * scratch_budget: device bytes the call may allocate for its working arrays (0 = 4 GiB); packs are processed in groups
  * that fit.  The call synchronises with `stream`.  Returns the number of packs that failed or a negative library error.
  */
@@ -271,6 +276,9 @@ typedef struct ixr_encode_desc {
     int32_t  data_size;   /* obj_count * 4 or * 8 */
     int32_t  pack_size;   /* out */
     int32_t  encode_type; /* out: IXR_ENC_DELTA or IXR_ENC_DICT_COMPRESS */
+    int64_t  min_value;   /* out: dpn.minValue */
+    int64_t  max_value;   /* out: dpn.maxValue */
+    int64_t  sum;         /* out: dpn.sum */
 } ixr_encode_desc;
 int32_t ixr_encode_run(int32_t device, ixr_encode_desc* descs, int32_t n, const void* d_data, uint64_t data_bytes,
                        void* d_out, uint64_t out_bytes, uint64_t scratch_budget, void* stream);

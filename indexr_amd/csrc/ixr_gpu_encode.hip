@@ -8,6 +8,7 @@
 // The bytes it writes are those of the host encoder in ixr_encode.cpp (and of the reference), pack for pack.
 //
 // Per group of packs:
+//   k_enc_stats  dpn.minValue / maxValue / sum (DataPackCreator_VLT.java:21-163)
 //   k_enc_keys   rows -> unsigned keys whose order is the dictionary's order (signed ints; Float/Double.compare with the
 //                NaNs collapsed); notes the first NaN row of a pack (its bits become the NaN entry)
 //   sort         rocprim::segmented_radix_sort_keys, one segment per pack (the one library primitive of this library)
@@ -56,6 +57,7 @@ struct EncMeta {
     int32_t pack_size;    // out: compressed size or a negative error
     int32_t encode_type;  // out
     int32_t pad[3];
+    int64_t min_value, max_value, sum;  // out: DataPackNode statistics
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -164,6 +166,114 @@ __global__ __launch_bounds__(1024) void k_enc_keys(const EncPack* __restrict__ p
         if (nan) atomicMin(&metas[pi].first_nan, (int32_t)i);
     }
     keys[P.key_off + i] = k;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_enc_stats: dpn.minValue / maxValue / sum as DataPackCreator_VLT computes them (DataPackCreator_VLT.java:21-163).
+//   INT / LONG      min, max, wrapping 64-bit sum
+//   FLOAT / DOUBLE  the fold min = Math.min(v, min), max = Math.max(v, max): -0.0 < 0.0, and a NaN replaces whatever was
+//                   there and stays until the next NaN, so both end as the last NaN of the pack when there is one; stored
+//                   as Double.doubleToRawLongBits of the (widened) value (NumType.java:93-107).  The sum is accumulated row
+//                   after row in the column's own precision (float sum / double sum), which no tree reduction reproduces:
+//                   the rows are staged through LDS and one thread adds them in order.
+// One workgroup of 256 threads per pack.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kStatThreads = 256, kStatTile = 2048;
+template <typename U>
+__global__ __launch_bounds__(kStatThreads) void k_enc_stats(const EncPack* __restrict__ packs, const int* __restrict__ list, EncMeta* __restrict__ metas,
+                                                            const uint8_t* __restrict__ data) {
+    using S = typename std::make_signed<U>::type;
+    using F = typename std::conditional<sizeof(U) == 4, float, double>::type;
+    __shared__ U s_tile[kStatTile];
+    __shared__ U s_min[kStatThreads / 64], s_max[kStatThreads / 64];
+    __shared__ unsigned long long s_sum[kStatThreads / 64];
+    __shared__ int s_nan[kStatThreads / 64];
+    const int pi = list[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const EncPack P = packs[pi];
+    const int n = P.obj_count;
+    const U* rows = (const U*)(data + P.src_off);
+    const bool fp = P.data_type == IXR_FLOAT || P.data_type == IXR_DOUBLE;
+    constexpr U sign = (U)1 << (sizeof(U) * 8 - 1);
+    U kmin = ~(U)0, kmax = 0;  // order-preserving unsigned keys
+    unsigned long long isum = 0;
+    int last_nan = -1;
+    F fsum = 0;
+    for (int base = 0; base < n; base += kStatTile) {
+#pragma unroll
+        for (int q = 0; q < kStatTile / kStatThreads; q++) {
+            const int i = base + q * kStatThreads + tid;
+            if (i < n) {
+                const U b = rows[i];
+                if (fp) {
+                    s_tile[q * kStatThreads + tid] = b;
+                    const bool nan = sizeof(U) == 4 ? (b & 0x7fffffffu) > 0x7f800000u : (b & 0x7fffffffffffffffull) > 0x7ff0000000000000ull;
+                    if (nan) last_nan = i;
+                    else {
+                        const U k = (b & sign) ? ~b : (b | sign);
+                        kmin = k < kmin ? k : kmin;
+                        kmax = k > kmax ? k : kmax;
+                    }
+                } else {
+                    const U k = b ^ sign;
+                    kmin = k < kmin ? k : kmin;
+                    kmax = k > kmax ? k : kmax;
+                    isum += (unsigned long long)(long long)(S)b;
+                }
+            }
+        }
+        if (fp) {  // workgroup-uniform
+            __syncthreads();
+            if (tid == 0) {
+                const int c = min(kStatTile, n - base);
+                for (int k = 0; k < c; k++) {
+                    F v;
+                    if constexpr (sizeof(U) == 4) v = __uint_as_float(s_tile[k]);
+                    else v = __longlong_as_double((long long)s_tile[k]);
+                    fsum += v;
+                }
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const U a = __shfl_xor(kmin, d), b = __shfl_xor(kmax, d);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+        isum += __shfl_xor(isum, d);
+        last_nan = max(last_nan, __shfl_xor(last_nan, d));
+    }
+    if (lane == 0) { s_min[wave] = kmin; s_max[wave] = kmax; s_sum[wave] = isum; s_nan[wave] = last_nan; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < kStatThreads / 64; w++) {
+            kmin = s_min[w] < kmin ? s_min[w] : kmin;
+            kmax = s_max[w] > kmax ? s_max[w] : kmax;
+            isum += s_sum[w];
+            last_nan = max(last_nan, s_nan[w]);
+        }
+        EncMeta& M = metas[pi];
+        if (!fp) {
+            M.min_value = (int64_t)(S)(kmin ^ sign);
+            M.max_value = (int64_t)(S)(kmax ^ sign);
+            M.sum = (int64_t)isum;
+        } else {
+            U bmin, bmax;
+            if (last_nan >= 0) bmin = bmax = rows[last_nan];
+            else {
+                bmin = (kmin & sign) ? (kmin ^ sign) : ~kmin;
+                bmax = (kmax & sign) ? (kmax ^ sign) : ~kmax;
+            }
+            if constexpr (sizeof(U) == 4) {
+                M.min_value = __double_as_longlong((double)__uint_as_float(bmin));
+                M.max_value = __double_as_longlong((double)__uint_as_float(bmax));
+            } else {
+                M.min_value = (int64_t)bmin;
+                M.max_value = (int64_t)bmax;
+            }
+            M.sum = __double_as_longlong((double)fsum);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -526,7 +636,7 @@ extern "C" int32_t ixr_encode_run(int32_t device, ixr_encode_desc* descs, int32_
         const uint64_t nn = (uint64_t)d.obj_count;
         need[(size_t)i] = 2 * align256(nn * w) /* keys in, keys sorted */ + align256(nn * w) + 3 * align256(nn * 2) + 3 * align256((nn + 1) * 4);
         per_pack_max = std::max(per_pack_max, need[(size_t)i]);
-        hm[(size_t)i] = EncMeta{INT32_MAX, 0, 0, 0, 0, {0, 0, 0}};
+        hm[(size_t)i] = EncMeta{INT32_MAX, 0, 0, 0, 0, {0, 0, 0}, 0, 0, 0};
     }
     if (scratch_budget == 0) scratch_budget = 4ull << 30;
     if (scratch_budget < per_pack_max) return set_error(IXR_ERR_INVALID_ARGUMENT, "scratch budget smaller than one pack needs");
@@ -622,6 +732,7 @@ extern "C" int32_t ixr_encode_run(int32_t device, ixr_encode_desc* descs, int32_
         if (gp.c32) {
             uint32_t* kin = (uint32_t*)(S + gp.k32_in);
             uint32_t* kout = (uint32_t*)(S + gp.k32_out);
+            hipLaunchKernelGGL(k_enc_stats<uint32_t>, dim3(gp.c32), dim3(kStatThreads), 0, st, P, l32, M, D);
             hipLaunchKernelGGL(k_enc_keys<uint32_t>, dim3(IXR_PACK_TILES, gp.c32), dim3(1024), 0, st, P, l32, M, D, kin);
             size_t t = temp_bytes;
             if (sort_segments<uint32_t>(d_temp.p, t, kin, kout, gp.t32, (unsigned)gp.c32, sg + g.first, sg + (size_t)n + g.first, st) != hipSuccess)
@@ -632,6 +743,7 @@ extern "C" int32_t ixr_encode_run(int32_t device, ixr_encode_desc* descs, int32_
         if (gp.c64) {
             uint64_t* kin = (uint64_t*)(S + gp.k64_in);
             uint64_t* kout = (uint64_t*)(S + gp.k64_out);
+            hipLaunchKernelGGL(k_enc_stats<uint64_t>, dim3(gp.c64), dim3(kStatThreads), 0, st, P, l64, M, D);
             hipLaunchKernelGGL(k_enc_keys<uint64_t>, dim3(IXR_PACK_TILES, gp.c64), dim3(1024), 0, st, P, l64, M, D, kin);
             size_t t = temp_bytes;
             if (sort_segments<uint64_t>(d_temp.p, t, kin, kout, gp.t64, (unsigned)gp.c64, sg + 2 * (size_t)n + g.first, sg + 3 * (size_t)n + g.first, st) != hipSuccess)
@@ -647,6 +759,9 @@ extern "C" int32_t ixr_encode_run(int32_t device, ixr_encode_desc* descs, int32_
     for (int i = 0; i < n; i++) {
         descs[i].pack_size = hm[(size_t)i].pack_size;
         descs[i].encode_type = hm[(size_t)i].encode_type;
+        descs[i].min_value = hm[(size_t)i].min_value;
+        descs[i].max_value = hm[(size_t)i].max_value;
+        descs[i].sum = hm[(size_t)i].sum;
         bad += descs[i].pack_size < 0;
     }
     return bad;

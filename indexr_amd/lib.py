@@ -69,7 +69,8 @@ class ScanFilterDesc(C.Structure):
 class EncodeDesc(C.Structure):
     """ixr_encode_desc: one decoded numeric pack to compress on the device (PackCompressor_VLT.compress)"""
     _fields_ = [("src_off", C.c_uint64), ("dst_off", C.c_uint64), ("data_type", C.c_int32), ("is_indexed", C.c_int32),
-                ("obj_count", C.c_int32), ("data_size", C.c_int32), ("pack_size", C.c_int32), ("encode_type", C.c_int32)]
+                ("obj_count", C.c_int32), ("data_size", C.c_int32), ("pack_size", C.c_int32), ("encode_type", C.c_int32),
+                ("min_value", C.c_int64), ("max_value", C.c_int64), ("sum", C.c_int64)]
 
 
 class SynthReq(C.Structure):

@@ -1353,3 +1353,46 @@ int ixo_scan_filter(int data_type, int n, const uint8_t* data, int data_size, in
 #undef SET
     return any ? 2 : 0;
 }
+
+/* DataPackCreator_VLT.from (indexr-vlt-segment/.../segment/pack/DataPackCreator_VLT.java:21-163): dpn.minValue / maxValue /
+ * sum of a numeric pack.  java.lang.Math.min / max on float and double: a NaN first argument is returned, -0.0 is below
+ * 0.0, otherwise <= / >=. */
+static float jmin_f(float a, float b) { if (a != a) return a; if (a == 0.0f && b == 0.0f && signbit(b)) return b; return a <= b ? a : b; }
+static float jmax_f(float a, float b) { if (a != a) return a; if (a == 0.0f && b == 0.0f && signbit(a)) return b; return a >= b ? a : b; }
+static double jmin_d(double a, double b) { if (a != a) return a; if (a == 0.0 && b == 0.0 && signbit(b)) return b; return a <= b ? a : b; }
+static double jmax_d(double a, double b) { if (a != a) return a; if (a == 0.0 && b == 0.0 && signbit(a)) return b; return a >= b ? a : b; }
+static int64_t double_bits(double d) { int64_t v; memcpy(&v, &d, 8); return v; }
+int ixo_pack_stats(int data_type, int n, const uint8_t* data, int64_t* min_value, int64_t* max_value, int64_t* sum) {
+    if (n < 1) return -1000;
+    switch (data_type) {
+        case IXO_INT: {  /* :21-46 */
+            int32_t mn, mx, v; uint64_t s = 0;
+            memcpy(&mn, data, 4); mx = mn;
+            for (int i = 0; i < n; i++) { memcpy(&v, data + 4 * (size_t)i, 4); if (v < mn) mn = v; if (v > mx) mx = v; s += (uint64_t)(int64_t)v; }
+            *min_value = mn; *max_value = mx; *sum = (int64_t)s;
+            return 0;
+        }
+        case IXO_LONG: {  /* :56-81 */
+            int64_t mn, mx, v; uint64_t s = 0;
+            memcpy(&mn, data, 8); mx = mn;
+            for (int i = 0; i < n; i++) { memcpy(&v, data + 8 * (size_t)i, 8); if (v < mn) mn = v; if (v > mx) mx = v; s += (uint64_t)v; }
+            *min_value = mn; *max_value = mx; *sum = (int64_t)s;
+            return 0;
+        }
+        case IXO_FLOAT: {  /* :91-118: float sum, NumType.floatToLong = raw bits of the widened value */
+            float mn, mx, v; volatile float s = 0;
+            memcpy(&mn, data, 4); mx = mn;
+            for (int i = 0; i < n; i++) { memcpy(&v, data + 4 * (size_t)i, 4); mn = jmin_f(v, mn); mx = jmax_f(v, mx); s = s + v; }
+            *min_value = double_bits((double)mn); *max_value = double_bits((double)mx); *sum = double_bits((double)s);
+            return 0;
+        }
+        case IXO_DOUBLE: {  /* :128-155 */
+            double mn, mx, v; volatile double s = 0;
+            memcpy(&mn, data, 8); mx = mn;
+            for (int i = 0; i < n; i++) { memcpy(&v, data + 8 * (size_t)i, 8); mn = jmin_d(v, mn); mx = jmax_d(v, mx); s = s + v; }
+            *min_value = double_bits(mn); *max_value = double_bits(mx); *sum = double_bits(s);
+            return 0;
+        }
+        default: return -102;
+    }
+}

@@ -107,6 +107,10 @@ int ixo_filter(int data_type, int encode_type, int n, const uint8_t* pack, int p
 int ixo_scan_filter(int data_type, int n, const uint8_t* data, int data_size, int op, int n_values,
                     const int64_t* num_values, const uint8_t* str_values, uint64_t* bitmap);
 
+/* DataPackCreator_VLT.from (indexr-vlt-segment/.../segment/pack/DataPackCreator_VLT.java:21-163): dpn.minValue, maxValue
+ * and sum of a numeric pack (floats: Math.min / Math.max fold, float / double running sum, raw bits of the widened value). */
+int ixo_pack_stats(int data_type, int n, const uint8_t* data, int64_t* min_value, int64_t* max_value, int64_t* sum);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,7 @@ for name, res, args in [
     ("ixo_filter", C.c_int, [C.c_int, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), _u8p, C.POINTER(C.c_uint64)]),
     ("ixo_scan_filter", C.c_int, [C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), _u8p, C.POINTER(C.c_uint64)]),
     ("ixo_like", C.c_int, [_u8p, C.c_int, _u8p, C.c_int]),
+    ("ixo_pack_stats", C.c_int, [C.c_int, C.c_int, _u8p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("ixo_handback", C.c_int, [C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]),
 ]:
     fn = getattr(lib, name)
@@ -177,3 +178,13 @@ def scan_filter_pack(data, data_type, n, op, keys):
         nv = np.asarray(keys, dtype=np.int64)
         r = lib.ixo_scan_filter(data_type, n, _p(data), len(data), op, len(keys), nv.ctypes.data_as(C.POINTER(C.c_int64)), None, bp)
     return r, bitmap
+
+
+def pack_stats(data, data_type, n):
+    """DataPackCreator_VLT's dpn statistics -> (minValue, maxValue, sum) as int64"""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    r = lib.ixo_pack_stats(data_type, n, _p(data), C.byref(a), C.byref(b), C.byref(c))
+    if r:
+        raise RuntimeError("ixo_pack_stats: %d" % r)
+    return a.value, b.value, c.value

@@ -74,6 +74,33 @@ def test_oracle_encoder_round_trips_the_test_columns():
         assert consumed == len(pack) and np.array_equal(back, data), name
 
 
+def as_double(bits):
+    return np.array([bits], dtype="<i8").view("<f8")[0]
+
+
+def test_oracle_pack_stats_follow_the_creator_loops():
+    """DataPackCreator_VLT.java:21-163 against numpy: integer min / max / wrapping sum; float columns fold Math.min / Math.max
+    and add row after row in their own precision (numpy's cumsum is that sequential sum)"""
+    rng = np.random.default_rng(3)
+    for name, dt, _, rows in columns(5000, rng):
+        mn, mx, sm = O.pack_stats(O.rows_to_bytes(rows, dt), dt, len(rows))
+        if dt in (O.INT, O.LONG):
+            assert (mn, mx) == (int(rows.min()), int(rows.max())), name
+            assert sm == int(np.sum(rows.astype(object)) + 2**63) % 2**64 - 2**63, name
+        else:
+            assert as_double(mn) == float(rows.min()) and as_double(mx) == float(rows.max()), name
+            assert as_double(sm) == float(np.cumsum(rows, dtype=rows.dtype)[-1]), name
+    # zeros of both signs, NaNs: the last NaN of the pack ends up in both min and max
+    z = np.array([0.0, -0.0, 0.0], dtype="<f4")
+    mn, mx, _ = O.pack_stats(O.rows_to_bytes(z, O.FLOAT), O.FLOAT, 3)
+    assert mn == np.array([-0.0], dtype="<f8").view("<i8")[0] and mx == 0
+    nan_a, nan_b = np.array([0x7fc00001, 0x7fc00777], dtype="<u4").view("<f4")
+    f = np.array([1.0, nan_a, -5.0, nan_b, 9.0], dtype="<f4")
+    mn, mx, sm = O.pack_stats(O.rows_to_bytes(f, O.FLOAT), O.FLOAT, 5)
+    want = np.array([nan_b], dtype="<f4").astype("<f8").view("<i8")[0]
+    assert mn == want and mx == want and np.isnan(as_double(sm))
+
+
 @pytest.mark.gpu
 def test_gpu_encoder_writes_the_bytes_of_the_reference_encoder():
     cases = build_cases()
@@ -84,7 +111,7 @@ def test_gpu_encoder_writes_the_bytes_of_the_reference_encoder():
         pad = -len(data) % 16
         parts.append(np.zeros(pad, dtype=np.uint8))
         cap = L.lib.ixr_compress_bound(len(rows), len(data))
-        descs.append(L.EncodeDesc(src, dst, dt, int(idx), len(rows), len(data), 0, 0))
+        descs.append(L.EncodeDesc(src, dst, dt, int(idx), len(rows), len(data), 0, 0, 0, 0, 0))
         src += len(data) + pad
         dst += (cap + 15) & ~15
     arena = np.concatenate(parts)
@@ -105,6 +132,12 @@ def test_gpu_encoder_writes_the_bytes_of_the_reference_encoder():
                 assert np.array_equal(got, want), (name, int(np.argmax(got != want)))
                 cap = L.lib.ixr_compress_bound(len(rows), len(rows) * (4 if dt in (O.INT, O.FLOAT) else 8))
                 assert (host[a.dst_off + a.pack_size:a.dst_off + cap] == 0xCD).all(), name  # nothing written past the pack
+                mn, mx, sm = O.pack_stats(O.rows_to_bytes(rows, dt), dt, len(rows))
+                assert (a.min_value, a.max_value) == (mn, mx), (name, a.min_value, mn, a.max_value, mx)
+                if dt in (O.FLOAT, O.DOUBLE) and np.isnan(as_double(sm)):
+                    assert np.isnan(as_double(a.sum)), name  # which NaN an addition hands on is the hardware's choice
+                else:
+                    assert a.sum == sm, (name, a.sum, sm)
                 types.add(et)
             assert types == {O.DELTA, O.DICT_COMPRESS}
             d_out.upload(np.full(dst, 0xCD, dtype=np.uint8))
@@ -123,7 +156,7 @@ def test_gpu_encoder_output_decodes_on_the_gpu():
         data = O.rows_to_bytes(rows, dt)
         parts.append(data)
         cap = L.lib.ixr_compress_bound(len(rows), len(data))
-        descs.append(L.EncodeDesc(src, dst, dt, int(idx), len(rows), len(data), 0, 0))
+        descs.append(L.EncodeDesc(src, dst, dt, int(idx), len(rows), len(data), 0, 0, 0, 0, 0))
         src += len(data)
         dst += (cap + 15) & ~15
     arena = np.concatenate(parts)
