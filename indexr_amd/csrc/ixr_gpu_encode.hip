@@ -40,7 +40,7 @@ struct EncPack {
     uint64_t src_off, dst_off;
     int32_t data_type, is_indexed, obj_count, dst_cap;
     int32_t max_entries;  // ceil((float)n * ratio), DictCodec.java:83
-    int32_t pad;
+    int32_t data_size;
     uint64_t key_off;     // element offset of the pack's keys in the group's key arrays (of its width)
     uint64_t s_entries;   // scratch: dictionary entries, raw bit patterns, obj_count * width bytes
     uint64_t s_ids;       // scratch: uint16 id per row
@@ -49,6 +49,13 @@ struct EncPack {
     uint64_t s_seg_of;    // scratch: uint16 segment index per run
     uint64_t s_segs;      // scratch: uint32 first row | RLE flag << 31 per segment, obj_count + 1 entries
     uint64_t s_pos;       // scratch: uint32 byte position of every segment
+    // string packs only
+    uint64_t s_perm;      // scratch: uint32 row index per sort slot, obj_count rounded up to a power of two
+    uint64_t s_ent_row;   // scratch: uint32 a row holding entry e
+    uint64_t s_pre;       // scratch: uint32 prefixLen per entry (front coding)
+    uint64_t s_suf;       // scratch: uint32 suffixLen per entry
+    uint64_t s_ent_off;   // scratch: uint32 offset of entry e in the dictionary body, obj_count + 1 entries
+    uint64_t s_suf_off;   // scratch: uint32 offset of entry e's suffix in the suffix bytes, obj_count + 1 entries
 };
 struct EncMeta {
     int32_t first_nan;    // first row holding a NaN (INT32_MAX: none)
@@ -582,6 +589,191 @@ __global__ __launch_bounds__(kEncThreads) void k_enc_pack(const EncPack* __restr
     if (tid == 0) { M.pack_size = rsz ? (int32_t)(9u + esz + rsz) : kEncOverflow; M.encode_type = IXR_ENC_DICT_COMPRESS; }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_enc_str: a string pack (StringsStruct: int32 offset[n+1] | bytes) -> DICT_COMPRESS, one workgroup per pack.
+//   DictCodec.encodeStrings :379-433 (sorted set of the distinct strings, BytesUtil.compareBytes order: unsigned bytes,
+//   then length), DictStructUtil.compress :25-81 (entries plain as a StringsStruct, or front coded by
+//   DeltaCodec.encodeStrings :268-352 when there are >= 64 entries in >= 256 bytes), ids as RLE / bit-packing hybrid.
+// Steps: the offsets are checked; a bitonic sort orders the row indices by their strings (compare-exchange pairs spread
+// over the workgroup, one barrier per stage); neighbours that differ start a dictionary entry, the entry number of a slot is
+// the id of the row in it; entry lengths, common prefixes with the entry before and their running sums give every byte its
+// place; the writers are those of the numeric packs.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kSortPad = 0xFFFFFFFFu;  // a slot past the last row: sorts after every string
+__device__ __forceinline__ int bytes_cmp(const uint8_t* a, int la, const uint8_t* b, int lb) {  // BytesUtil.compareBytes :7-19
+    const int l = min(la, lb);
+    int i = 0;
+    for (; i + 8 <= l; i += 8) {
+        uint64_t x, y;
+        __builtin_memcpy(&x, a + i, 8);
+        __builtin_memcpy(&y, b + i, 8);
+        if (x != y) {
+            const int sh = (__ffsll((long long)(x ^ y)) - 1) & ~7;  // the first byte that differs is the lowest one in a little-endian word
+            return (int)((x >> sh) & 0xff) - (int)((y >> sh) & 0xff);
+        }
+    }
+    for (; i < l; i++) {
+        const int c = (int)a[i] - (int)b[i];
+        if (c) return c;
+    }
+    return la - lb;
+}
+struct StrRows {
+    const int32_t* off;
+    const uint8_t* body;
+    __device__ __forceinline__ int cmp(uint32_t ra, uint32_t rb) const {
+        const int32_t a0 = off[ra], a1 = off[ra + 1], b0 = off[rb], b1 = off[rb + 1];
+        return bytes_cmp(body + a0, a1 - a0, body + b0, b1 - b0);
+    }
+    // the sort's total order: strings, equal strings by row, padding last
+    __device__ __forceinline__ bool after(uint32_t ra, uint32_t rb) const {
+        if (ra == rb || rb == kSortPad) return false;
+        if (ra == kSortPad) return true;
+        const int c = cmp(ra, rb);
+        return c > 0 || (c == 0 && ra > rb);
+    }
+};
+
+__global__ __launch_bounds__(kEncThreads) void k_enc_str(const EncPack* __restrict__ packs, const int* __restrict__ list, EncMeta* __restrict__ metas,
+                                                         const uint8_t* __restrict__ data, uint8_t* __restrict__ out, uint8_t* __restrict__ scratch) {
+    __shared__ uint32_t s_w[kEncWaves + 1];
+    __shared__ DeltaLds<uint32_t> s_delta;
+    __shared__ int s_bad;
+    const int pi = list[blockIdx.x];
+    const EncPack P = packs[pi];
+    EncMeta& M = metas[pi];
+    const int n = P.obj_count, tid = threadIdx.x;
+    const int32_t* off = (const int32_t*)(data + P.src_off);
+    const StrRows S{off, data + P.src_off + 4ull * ((uint32_t)n + 1)};
+    const int64_t total = (int64_t)P.data_size - 4ll * (n + 1);
+    uint8_t* dst = out + P.dst_off;
+    const uint32_t cap = (uint32_t)P.dst_cap;
+    // the offsets index the body: ascending, inside it, the last one its size (what the host encoder asks of its input)
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    {
+        bool bad = false;
+        for (int i = tid; i < n; i += kEncThreads) {
+            const int32_t a = off[i], b = off[i + 1];
+            if (a < 0 || b < a || (int64_t)b > total) bad = true;
+        }
+        if (tid == 0 && (int64_t)off[n] != total) bad = true;
+        if (bad) s_bad = 1;
+    }
+    __syncthreads();
+    if (s_bad) { if (tid == 0) M.pack_size = IXR_ERR_INVALID_ARGUMENT; return; }
+    // sort
+    uint32_t* perm = (uint32_t*)(scratch + P.s_perm);
+    uint32_t n2 = 2;
+    while (n2 < (uint32_t)n) n2 <<= 1;
+    for (uint32_t i = tid; i < n2; i += kEncThreads) perm[i] = i < (uint32_t)n ? i : kSortPad;
+    __syncthreads();
+    for (uint32_t k = 2; k <= n2; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < n2 / 2; t += kEncThreads) {
+                const uint32_t i = 2 * j * (t / j) + (t % j), l = i + j;
+                const uint32_t a = perm[i], b = perm[l];
+                const bool up = (i & k) == 0;
+                if (S.after(a, b) == up && a != b) { perm[i] = b; perm[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    // entries and ids
+    uint16_t* ids = (uint16_t*)(scratch + P.s_ids);
+    uint32_t* ent_row = (uint32_t*)(scratch + P.s_ent_row);
+    uint32_t carry = 0;
+    for (int base = 0; base < n; base += kEncThreads) {
+        const int j = base + tid;
+        bool head = false;
+        uint32_t r = 0;
+        if (j < n) {
+            r = perm[j];
+            head = j == 0 || S.cmp(perm[j - 1], r) != 0;
+        }
+        uint32_t tot;
+        const uint32_t ex = wg_excl_scan(head ? 1u : 0u, s_w, &tot);
+        if (j < n) ids[r] = (uint16_t)(carry + ex + (head ? 1u : 0u) - 1u);
+        if (head) ent_row[carry + ex] = r;
+        carry += tot;
+    }
+    const int ec = (int)carry;
+    __syncthreads();
+    // entry lengths, prefixes, running sums
+    uint32_t* pre = (uint32_t*)(scratch + P.s_pre);
+    uint32_t* suf = (uint32_t*)(scratch + P.s_suf);
+    uint32_t* ent_off = (uint32_t*)(scratch + P.s_ent_off);
+    uint32_t* suf_off = (uint32_t*)(scratch + P.s_suf_off);
+    uint32_t len_carry = 0, suf_carry = 0;
+    for (int base = 0; base < ec; base += kEncThreads) {
+        const int e = base + tid;
+        uint32_t len = 0, p = 0;
+        if (e < ec) {
+            const uint32_t r = ent_row[e];
+            const int32_t a0 = off[r];
+            len = (uint32_t)(off[r + 1] - a0);
+            if (e > 0) {
+                const uint32_t q = ent_row[e - 1];
+                const int32_t b0 = off[q];
+                const uint32_t lim = min(len, (uint32_t)(off[q + 1] - b0));
+                while (p < lim && S.body[a0 + p] == S.body[b0 + p]) p++;
+            }
+            pre[e] = p;
+            suf[e] = len - p;
+        }
+        uint32_t tot;
+        uint32_t ex = wg_excl_scan(len, s_w, &tot);
+        if (e < ec) ent_off[e] = len_carry + ex;
+        len_carry += tot;
+        ex = wg_excl_scan(len - p, s_w, &tot);
+        if (e < ec) suf_off[e] = suf_carry + ex;
+        suf_carry += tot;
+    }
+    __syncthreads();
+    const uint32_t body_bytes = len_carry, suf_bytes = suf_carry;
+    const uint64_t dict_size = 4ull * ((uint32_t)ec + 1) + body_bytes;
+    const bool compressed = ec >= 64 && dict_size >= 256;  // DictStructUtil.java:26-27
+    if (tid == 0) {
+        put_u32(dst, (uint32_t)(4u + dict_size + 4u + 4ull * (uint32_t)n));  // size of the uncompressed DictStruct
+        put_u32(dst + 4, (uint32_t)ec);
+        dst[8] = compressed ? 1 : 0;
+    }
+    uint32_t esz;
+    if (!compressed) {
+        if (9ull + dict_size > (uint64_t)cap) { if (tid == 0) M.pack_size = kEncOverflow; return; }
+        uint8_t* idx = dst + 9;
+        uint8_t* bytes = idx + 4ull * ((uint32_t)ec + 1);
+        for (int e = tid; e <= ec; e += kEncThreads) put_u32(idx + 4ull * e, e < ec ? ent_off[e] : body_bytes);
+        for (int e = tid; e < ec; e += kEncThreads) {
+            const uint32_t r = ent_row[e];
+            const uint8_t* sp = S.body + off[r];
+            const uint32_t len = (uint32_t)(off[r + 1] - off[r]), at = ent_off[e];
+            for (uint32_t k = 0; k < len; k++) bytes[at + k] = sp[k];
+        }
+        esz = (uint32_t)dict_size;
+    } else {
+        uint8_t* base = dst + 9;
+        const uint32_t d1 = wg_delta_encode<uint32_t>(pre, ec, base + 4, cap - 13, s_delta, s_w);
+        if (!d1) { if (tid == 0) M.pack_size = kEncOverflow; return; }
+        __syncthreads();
+        const uint32_t d2 = wg_delta_encode<uint32_t>(suf, ec, base + 4 + d1, cap - 13 - d1, s_delta, s_w);
+        if (!d2 || 13ull + d1 + d2 + suf_bytes > (uint64_t)cap) { if (tid == 0) M.pack_size = kEncOverflow; return; }
+        uint8_t* bytes = base + 4 + d1 + d2;
+        for (int e = tid; e < ec; e += kEncThreads) {
+            const uint32_t r = ent_row[e], p = pre[e], len = suf[e], at = suf_off[e];
+            const uint8_t* sp = S.body + off[r] + p;
+            for (uint32_t k = 0; k < len; k++) bytes[at + k] = sp[k];
+        }
+        if (tid == 0) put_u32(base, d1 + d2 + suf_bytes);
+        esz = 4u + d1 + d2 + suf_bytes;
+    }
+    __syncthreads();
+    const int bw = bit_width64((uint64_t)(uint32_t)(ec - 1));
+    const uint32_t rsz = wg_rle_encode(ids, n, bw, dst + 9 + esz, cap - 9 - esz, (uint16_t*)(scratch + P.s_run_of), (uint32_t*)(scratch + P.s_heads),
+                                       (uint16_t*)(scratch + P.s_seg_of), (uint32_t*)(scratch + P.s_segs), (uint32_t*)(scratch + P.s_pos), s_w);
+    if (tid == 0) { M.entry_count = ec; M.use_dict = 1; M.pack_size = rsz ? (int32_t)(9u + esz + rsz) : kEncOverflow; M.encode_type = IXR_ENC_DICT_COMPRESS; }
+}
+
 }  // namespace ixr
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -600,6 +792,31 @@ struct DevMem {
     ~DevMem() { if (p) (void)hipFree(p); }
     bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess; }
 };
+// Lays the per-pack working arrays of `p` out from byte `off` of the group's scratch; returns the first byte after them.
+uint64_t layout_pack(EncPack& p, uint64_t off) {
+    const uint64_t nn = (uint64_t)p.obj_count;
+    auto take = [&](uint64_t bytes) { const uint64_t at = off; off += align256(bytes); return at; };
+    p.s_ids = take(nn * 2);
+    p.s_run_of = take(nn * 2);
+    p.s_seg_of = take(nn * 2);
+    p.s_heads = take((nn + 1) * 4);
+    p.s_segs = take((nn + 1) * 4);
+    p.s_pos = take((nn + 1) * 4);
+    p.s_entries = p.s_perm = p.s_ent_row = p.s_pre = p.s_suf = p.s_ent_off = p.s_suf_off = 0;
+    if (p.data_type == IXR_STRING) {
+        uint64_t n2 = 2;
+        while (n2 < nn) n2 <<= 1;
+        p.s_perm = take(n2 * 4);
+        p.s_ent_row = take(nn * 4);
+        p.s_pre = take(nn * 4);
+        p.s_suf = take(nn * 4);
+        p.s_ent_off = take((nn + 1) * 4);
+        p.s_suf_off = take((nn + 1) * 4);
+    } else {
+        p.s_entries = take(nn * ((p.data_type == IXR_INT || p.data_type == IXR_FLOAT) ? 4 : 8));
+    }
+    return off;
+}
 template <typename U>
 hipError_t sort_segments(void* temp, size_t& temp_bytes, U* in, U* out, unsigned total, unsigned segments, const unsigned* begins, const unsigned* ends, hipStream_t st) {
     return rocprim::segmented_radix_sort_keys(temp, temp_bytes, in, out, total, segments, begins, ends, 0, (unsigned)(sizeof(U) * 8), st);
@@ -622,19 +839,20 @@ extern "C" int32_t ixr_encode_run(int32_t device, ixr_encode_desc* descs, int32_
         ixr_encode_desc& d = descs[i];
         d.pack_size = IXR_ERR_BUG;
         d.encode_type = 0;
-        if (d.data_type < IXR_INT || d.data_type > IXR_DOUBLE) return set_error(IXR_ERR_UNSUPPORTED_TYPE, "encode descriptor: only INT, LONG, FLOAT and DOUBLE packs are encoded on the device");
+        if (d.data_type < IXR_INT || d.data_type > IXR_STRING) return set_error(IXR_ERR_UNSUPPORTED_TYPE, "encode descriptor: unknown data type");
+        const bool str = d.data_type == IXR_STRING;
         const int w = (d.data_type == IXR_INT || d.data_type == IXR_FLOAT) ? 4 : 8;
-        if (d.obj_count < 1 || d.obj_count > IXR_PACK_MAX_ROWS || (int64_t)d.obj_count * w != (int64_t)d.data_size)
+        if (d.obj_count < 1 || d.obj_count > IXR_PACK_MAX_ROWS || d.data_size < 0 ||
+            (str ? (int64_t)d.data_size < 4 * ((int64_t)d.obj_count + 1) : (int64_t)d.obj_count * w != (int64_t)d.data_size))
             return set_error(IXR_ERR_INVALID_ARGUMENT, "encode descriptor: row count and data size do not agree");
         if ((d.src_off & 15) || d.src_off + (uint64_t)d.data_size > data_bytes) return set_error(IXR_ERR_INVALID_ARGUMENT, "encode descriptor: rows outside the data arena");
         const int32_t cap = ixr_compress_bound(d.obj_count, d.data_size);
         if ((d.dst_off & 15) || d.dst_off + (uint64_t)cap > out_bytes) return set_error(IXR_ERR_INVALID_ARGUMENT, "encode descriptor: output slot outside the output arena");
         EncPack& p = hp[(size_t)i];
         p.src_off = d.src_off; p.dst_off = d.dst_off; p.data_type = d.data_type; p.is_indexed = d.is_indexed ? 1 : 0;
-        p.obj_count = d.obj_count; p.dst_cap = cap; p.pad = 0;
+        p.obj_count = d.obj_count; p.dst_cap = cap; p.data_size = d.data_size;
         p.max_entries = max_entries(d.obj_count, (d.data_type == IXR_INT && !d.is_indexed) ? 0.2f : 1.0f);  // PackCompressor_VLT.java:29-96
-        const uint64_t nn = (uint64_t)d.obj_count;
-        need[(size_t)i] = 2 * align256(nn * w) /* keys in, keys sorted */ + align256(nn * w) + 3 * align256(nn * 2) + 3 * align256((nn + 1) * 4);
+        need[(size_t)i] = layout_pack(p, 0) + (str ? 0 : 2 * align256((uint64_t)d.obj_count * w)) /* keys in, keys sorted */;
         per_pack_max = std::max(per_pack_max, need[(size_t)i]);
         hm[(size_t)i] = EncMeta{INT32_MAX, 0, 0, 0, 0, {0, 0, 0}, 0, 0, 0};
     }
@@ -656,12 +874,12 @@ extern "C" int32_t ixr_encode_run(int32_t device, ixr_encode_desc* descs, int32_
     }
     DevMem d_packs, d_metas, d_scratch, d_list, d_seg, d_temp;
     if (!d_packs.alloc(sizeof(EncPack) * (size_t)n) || !d_metas.alloc(sizeof(EncMeta) * (size_t)n) || !d_scratch.alloc(max_group + 256) ||
-        !d_list.alloc(sizeof(int) * (size_t)n * 2) || !d_seg.alloc(sizeof(unsigned) * (size_t)n * 4))
+        !d_list.alloc(sizeof(int) * (size_t)n * 3) || !d_seg.alloc(sizeof(unsigned) * (size_t)n * 4))
         return set_error(IXR_ERR_OUT_OF_MEMORY, "hipMalloc failed");
     // scratch layout per group: [keys32 in][keys32 sorted][keys64 in][keys64 sorted][per pack arrays]
-    std::vector<int> lists((size_t)n * 2);
+    std::vector<int> lists((size_t)n * 3);
     std::vector<unsigned> segs((size_t)n * 4);
-    struct GroupPlan { int c32, c64; uint64_t k32_in, k32_out, k64_in, k64_out; unsigned t32, t64; };
+    struct GroupPlan { int c32, c64, cstr; uint64_t k32_in, k32_out, k64_in, k64_out; unsigned t32, t64; };
     std::vector<GroupPlan> plans;
     size_t temp_bytes = 0;
     for (const Group& g : groups) {
@@ -669,13 +887,16 @@ extern "C" int32_t ixr_encode_run(int32_t device, ixr_encode_desc* descs, int32_
         uint64_t e32 = 0, e64 = 0;
         int* l32 = lists.data() + g.first;
         int* l64 = lists.data() + (size_t)n + g.first;
+        int* lstr = lists.data() + 2 * (size_t)n + g.first;
         unsigned* b32 = segs.data() + g.first;
         unsigned* e32p = segs.data() + (size_t)n + g.first;
         unsigned* b64 = segs.data() + 2 * (size_t)n + g.first;
         unsigned* e64p = segs.data() + 3 * (size_t)n + g.first;
         for (int i = g.first; i < g.first + g.count; i++) {
             EncPack& p = hp[(size_t)i];
-            if (p.data_type == IXR_INT || p.data_type == IXR_FLOAT) {
+            if (p.data_type == IXR_STRING) {
+                p.key_off = 0; lstr[gp.cstr++] = i;
+            } else if (p.data_type == IXR_INT || p.data_type == IXR_FLOAT) {
                 p.key_off = e32; b32[gp.c32] = (unsigned)e32; e32 += (uint64_t)p.obj_count; e32p[gp.c32] = (unsigned)e32; l32[gp.c32++] = i;
             } else {
                 p.key_off = e64; b64[gp.c64] = (unsigned)e64; e64 += (uint64_t)p.obj_count; e64p[gp.c64] = (unsigned)e64; l64[gp.c64++] = i;
@@ -687,17 +908,7 @@ extern "C" int32_t ixr_encode_run(int32_t device, ixr_encode_desc* descs, int32_
         gp.k32_out = off; off += align256(e32 * 4);
         gp.k64_in = off; off += align256(e64 * 8);
         gp.k64_out = off; off += align256(e64 * 8);
-        for (int i = g.first; i < g.first + g.count; i++) {
-            EncPack& p = hp[(size_t)i];
-            const uint64_t nn = (uint64_t)p.obj_count, w = (p.data_type == IXR_INT || p.data_type == IXR_FLOAT) ? 4 : 8;
-            p.s_entries = off; off += align256(nn * w);
-            p.s_ids = off; off += align256(nn * 2);
-            p.s_run_of = off; off += align256(nn * 2);
-            p.s_seg_of = off; off += align256(nn * 2);
-            p.s_heads = off; off += align256((nn + 1) * 4);
-            p.s_segs = off; off += align256((nn + 1) * 4);
-            p.s_pos = off; off += align256((nn + 1) * 4);
-        }
+        for (int i = g.first; i < g.first + g.count; i++) off = layout_pack(hp[(size_t)i], off);
         if (off > max_group + 256 + 4 * 256) return set_error(IXR_ERR_BUG, "encode scratch layout exceeds its allocation");
         // temporary storage of the sort: the largest any group asks for
         size_t t = 0;
@@ -714,7 +925,7 @@ extern "C" int32_t ixr_encode_run(int32_t device, ixr_encode_desc* descs, int32_
     if (!d_temp.alloc(temp_bytes + 256)) return set_error(IXR_ERR_OUT_OF_MEMORY, "hipMalloc failed");
     if (hipMemcpyAsync(d_packs.p, hp.data(), sizeof(EncPack) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess ||
         hipMemcpyAsync(d_metas.p, hm.data(), sizeof(EncMeta) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(d_list.p, lists.data(), sizeof(int) * (size_t)n * 2, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(d_list.p, lists.data(), sizeof(int) * (size_t)n * 3, hipMemcpyHostToDevice, st) != hipSuccess ||
         hipMemcpyAsync(d_seg.p, segs.data(), sizeof(unsigned) * (size_t)n * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)  // the host vectors are pageable memory
         return set_error(IXR_ERR_HIP, "H2D failed");
@@ -750,6 +961,10 @@ extern "C" int32_t ixr_encode_run(int32_t device, ixr_encode_desc* descs, int32_
                 return set_error(IXR_ERR_HIP, "segmented sort failed");
             hipLaunchKernelGGL(k_enc_dict<uint64_t>, dim3(gp.c64), dim3(kEncThreads), 0, st, P, l64, M, D, (const uint64_t*)kout, S);
             hipLaunchKernelGGL(k_enc_pack<uint64_t>, dim3(gp.c64), dim3(kEncThreads), 0, st, P, l64, M, D, O, S);
+        }
+        if (gp.cstr) {
+            const int* lstr = (const int*)d_list.p + 2 * (size_t)n + g.first;
+            hipLaunchKernelGGL(k_enc_str, dim3(gp.cstr), dim3(kEncThreads), 0, st, P, lstr, M, D, O, S);
         }
         if (hipGetLastError() != hipSuccess) return set_error(IXR_ERR_HIP, "kernel launch failed");
     }

@@ -47,9 +47,32 @@ def special_columns():
             ("f_zeros", O.FLOAT, False, np.array([-0.0, 0.0] * 40, dtype="<f4"))]
 
 
-def build_cases():
+def string_columns(n, rng):
+    doms = [bytes(rng.integers(97, 123, rng.integers(4, 13)).astype(np.uint8)) for _ in range(200)]
+    urls = [b"www." + doms[rng.integers(0, 200)] + b".com/" + bytes(rng.integers(48, 123, rng.integers(1, 50)).astype(np.uint8)) for _ in range(5000)]
+    zipf = np.minimum(rng.zipf(1.3, n) - 1, len(urls) - 1)
+    cats = [bytes(rng.integers(97, 123, rng.integers(3, 13)).astype(np.uint8)) for _ in range(32)]
+    raw = [bytes(rng.integers(0, 256, rng.integers(0, 12)).astype(np.uint8)) for _ in range(300)]  # every byte value: unsigned order
+    return [
+        ("s_cat", O.STRING, False, [cats[i] for i in rng.integers(0, 32, n)]),
+        ("s_url", O.STRING, False, [urls[i] for i in zipf]),
+        ("s_uniq", O.STRING, True, [bytes(rng.integers(48, 123, rng.integers(0, 25)).astype(np.uint8)) + b"%d" % i for i in range(n)]),
+        ("s_empty", O.STRING, False, [b"" if rng.random() < 0.9 else b"x%d" % rng.integers(0, 50) for _ in range(n)]),
+        ("s_raw", O.STRING, False, [raw[i] for i in rng.integers(0, 300, n)]),
+        ("s_runs", O.STRING, True, [cats[i] for i in np.repeat(rng.integers(0, 8, n // 16 + 1), 16)[:n]]),
+    ]
+
+
+def build_cases(strings=True):
     rng = np.random.default_rng(2024)
     cases = []
+    if strings:
+        cases += string_columns(65536, rng) + string_columns(3000, rng)
+        for n in (1, 2, 3, 63, 64, 65, 100):
+            cases.append(("s_small%d" % n, O.STRING, False, [b"k%03d" % (i * 7 % 90) for i in range(n)]))
+            cases.append(("s_allempty%d" % n, O.STRING, False, [b""] * n))
+        cases.append(("s_prefixes", O.STRING, False, [b"ab", b"abc", b"ab\x00", b"a", b"", b"abc", b"ab\xff", b"b"] * 20))
+        cases.append(("s_long", O.STRING, False, [bytes([65 + i % 7]) * (2000 + i % 5) + b"%d" % (i % 70) for i in range(300)]))
     for n in (65536, 12345):
         cases += columns(n, rng)
     for n in (1, 2, 7, 8, 9, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 257, 1023, 1025):
@@ -67,7 +90,8 @@ def build_cases():
 
 def test_oracle_encoder_round_trips_the_test_columns():
     """the packs the GPU encoder is compared with decode back to their rows (bit patterns; float specials excepted)"""
-    for name, dt, idx, rows in build_cases()[:40]:
+    cases = build_cases()
+    for name, dt, idx, rows in cases[:16] + cases[28:60]:
         data = O.rows_to_bytes(rows, dt)
         pack, et = O.compress_pack(data, dt, len(rows), idx)
         back, consumed = O.decompress_pack(pack, dt, et, len(rows), len(data))
@@ -119,7 +143,7 @@ def test_gpu_encoder_writes_the_bytes_of_the_reference_encoder():
     try:
         d_data.upload(arena)
         d_out.upload(np.full(dst, 0xCD, dtype=np.uint8))
-        for budget in (0, 24 << 20):  # one group; several groups
+        for budget in (0, 40 << 20):  # one group; several groups
             arr, bad = L.encode_run(descs, d_data.ptr, len(arena), d_out.ptr, dst, scratch_budget=budget)
             assert bad == 0, [(c[0], a.pack_size) for c, a in zip(cases, arr) if a.pack_size < 0]
             host = d_out.download()
@@ -130,8 +154,11 @@ def test_gpu_encoder_writes_the_bytes_of_the_reference_encoder():
                 assert a.pack_size == len(want), (name, a.pack_size, len(want))
                 got = host[a.dst_off:a.dst_off + a.pack_size]
                 assert np.array_equal(got, want), (name, int(np.argmax(got != want)))
-                cap = L.lib.ixr_compress_bound(len(rows), len(rows) * (4 if dt in (O.INT, O.FLOAT) else 8))
+                cap = L.lib.ixr_compress_bound(len(rows), a.data_size)
                 assert (host[a.dst_off + a.pack_size:a.dst_off + cap] == 0xCD).all(), name  # nothing written past the pack
+                if dt == O.STRING:
+                    assert (a.min_value, a.max_value, a.sum) == (0, 0, 0), name  # string packs carry no statistics
+                    continue
                 mn, mx, sm = O.pack_stats(O.rows_to_bytes(rows, dt), dt, len(rows))
                 assert (a.min_value, a.max_value) == (mn, mx), (name, a.min_value, mn, a.max_value, mx)
                 if dt in (O.FLOAT, O.DOUBLE) and np.isnan(as_double(sm)):
@@ -150,14 +177,16 @@ def test_gpu_encoder_writes_the_bytes_of_the_reference_encoder():
 def test_gpu_encoder_output_decodes_on_the_gpu():
     """encode -> decode round trip on the device: the decoder gets the packs where the encoder left them"""
     rng = np.random.default_rng(7)
-    cols = columns(65536, rng)
+    cols = columns(65536, rng) + string_columns(65536, rng)
     descs, parts, src, dst = [], [], 0, 0
     for name, dt, idx, rows in cols:
         data = O.rows_to_bytes(rows, dt)
         parts.append(data)
+        pad = -len(data) % 16
+        parts.append(np.zeros(pad, dtype=np.uint8))
         cap = L.lib.ixr_compress_bound(len(rows), len(data))
         descs.append(L.EncodeDesc(src, dst, dt, int(idx), len(rows), len(data), 0, 0, 0, 0, 0))
-        src += len(data)
+        src += len(data) + pad
         dst += (cap + 15) & ~15
     arena = np.concatenate(parts)
     d_data, d_cmp, d_back = L.DeviceBuffer(0, len(arena)), L.DeviceBuffer(0, dst + L.IN_SLACK), L.DeviceBuffer(0, len(arena) + 16)
@@ -171,7 +200,9 @@ def test_gpu_encoder_output_decodes_on_the_gpu():
         plan.run(d_cmp.ptr, dst + L.IN_SLACK, d_back.ptr, len(arena) + 16)
         status, nbad = plan.status()
         assert nbad == 0, status
-        assert np.array_equal(d_back.download()[:len(arena)], arena)
+        back = d_back.download()
+        for a in arr:
+            assert np.array_equal(back[a.src_off:a.src_off + a.data_size], arena[a.src_off:a.src_off + a.data_size]), a.data_type
     finally:
         if plan is not None:
             plan.destroy()
