@@ -460,9 +460,9 @@ def time_filter(L, np, device, sample, scratch_gib):
 
 
 def time_encode(L, np, device, sample, scratch_gib):
-    """Device encoder on the numeric packs of the first chunk: the chunk is decoded, its numeric packs are compressed again
-    by ixr_encode_run, and the result must be the packs the decode started from, byte for byte (those came from the host
-    encoder, whose output the tests pin to the oracle's)."""
+    """Device encoder on the first chunk: the chunk is decoded, its packs are compressed again by ixr_encode_run (numeric
+    packs and string packs timed apart), and the result must be the packs the decode started from, byte for byte (those
+    came from the host encoder, whose output the tests pin to the oracle's)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     descs, arena = sample
@@ -472,45 +472,51 @@ def time_encode(L, np, device, sample, scratch_gib):
     d_in.upload(arena)
     plan.run(d_in.ptr, in_bytes, d_dec.ptr, out_bytes)
     _, bad = plan.status()
-    num = [d for d in descs if d.data_type != 5]
-    ed, dst = [], 0
-    for d in num:
-        ed.append(L.EncodeDesc(d.out_off, dst, d.data_type, 0, d.obj_count, d.data_size, 0, 0, 0, 0, 0))
-        dst += (L.lib.ixr_compress_bound(d.obj_count, d.data_size) + 15) & ~15
-    d_cmp = L.DeviceBuffer(device, dst)
-    best = None
-    for it in range(3):
-        L.lib.ixr_dev_synchronize(device)
-        t = time.perf_counter()
-        arr, nbad = L.encode_run(ed, d_dec.ptr, out_bytes, d_cmp.ptr, dst, device=device, scratch_budget=int(scratch_gib * (1 << 30)))
-        dt = time.perf_counter() - t
-        if it and (best is None or dt < best):
-            best = dt
-    host = d_cmp.download()
-    same = 0
-    for d, a in zip(num, arr):
-        if a.pack_size != d.pack_size or a.encode_type != d.encode_type or not (host[a.dst_off:a.dst_off + a.pack_size] == arena[d.in_off:d.in_off + d.pack_size]).all():
-            raise SystemExit("device encoder differs from the host encoder on the pack at %d" % d.in_off)
-        same += 1
-    # the oracle's encoder on one host thread, a few packs of every type
-    dec = d_dec.download()
-    cpu_s, cpu_rows, seen = 0.0, 0, {}
-    for d in num:
-        if seen.get(d.data_type, 0) >= 3:
+    dec = None
+    res = {}
+    for label, chosen in (("numeric", [d for d in descs if d.data_type != 5]), ("strings", [d for d in descs if d.data_type == 5])):
+        if not chosen:
             continue
-        seen[d.data_type] = seen.get(d.data_type, 0) + 1
-        rows = dec[d.out_off:d.out_off + d.data_size]
-        t = time.perf_counter()
-        O.compress_pack(rows, d.data_type, d.obj_count, False)
-        cpu_s += time.perf_counter() - t
-        cpu_rows += d.obj_count
-    rows_total = sum(d.obj_count for d in num)
-    raw = sum(d.data_size for d in num)
-    res = {"rows_per_s": round(rows_total / best, 1), "raw_GBps_in": round(raw / best / 1e9, 2), "packs": len(num), "ms": round(best * 1e3, 3),
-           "compressed_GB": round(sum(a.pack_size for a in arr) / 1e9, 3), "raw_GB": round(raw / 1e9, 3), "bad": int(nbad) + int(bad),
-           "identical_to_host_encoder": same, "cpu_oracle_rows_per_s_1_thread": round(cpu_rows / cpu_s, 1),
-           "note": "wall time of ixr_encode_run (keys, segmented sort, dictionary, ids, DELTA / RLE writers; incl. allocations, uploads, result download, sync)"}
-    plan.destroy(); d_in.free(); d_dec.free(); d_cmp.free()
+        ed, dst = [], 0
+        for d in chosen:
+            ed.append(L.EncodeDesc(d.out_off, dst, d.data_type, 0, d.obj_count, d.data_size, 0, 0, 0, 0, 0))
+            dst += (L.lib.ixr_compress_bound(d.obj_count, d.data_size) + 15) & ~15
+        d_cmp = L.DeviceBuffer(device, dst)
+        best = None
+        for it in range(3):
+            L.lib.ixr_dev_synchronize(device)
+            t = time.perf_counter()
+            arr, nbad = L.encode_run(ed, d_dec.ptr, out_bytes, d_cmp.ptr, dst, device=device, scratch_budget=int(scratch_gib * (1 << 30)))
+            dt = time.perf_counter() - t
+            if it and (best is None or dt < best):
+                best = dt
+        host = d_cmp.download()
+        same = 0
+        for d, a in zip(chosen, arr):
+            if a.pack_size != d.pack_size or a.encode_type != d.encode_type or not (host[a.dst_off:a.dst_off + a.pack_size] == arena[d.in_off:d.in_off + d.pack_size]).all():
+                raise SystemExit("device encoder differs from the host encoder on the pack at %d" % d.in_off)
+            same += 1
+        # the oracle's encoder on one host thread, a few packs of every type
+        if dec is None:
+            dec = d_dec.download()
+        cpu_s, cpu_rows, seen = 0.0, 0, {}
+        for d in chosen:
+            if seen.get(d.data_type, 0) >= 3:
+                continue
+            seen[d.data_type] = seen.get(d.data_type, 0) + 1
+            rows = dec[d.out_off:d.out_off + d.data_size]
+            t = time.perf_counter()
+            O.compress_pack(rows, d.data_type, d.obj_count, False)
+            cpu_s += time.perf_counter() - t
+            cpu_rows += d.obj_count
+        rows_total = sum(d.obj_count for d in chosen)
+        raw = sum(d.data_size for d in chosen)
+        res[label] = {"rows_per_s": round(rows_total / best, 1), "raw_GBps_in": round(raw / best / 1e9, 2), "packs": len(chosen), "ms": round(best * 1e3, 3),
+                      "compressed_GB": round(sum(a.pack_size for a in arr) / 1e9, 3), "raw_GB": round(raw / 1e9, 3), "bad": int(nbad) + int(bad),
+                      "identical_to_host_encoder": same, "cpu_oracle_rows_per_s_1_thread": round(cpu_rows / cpu_s, 1)}
+        d_cmp.free()
+    res["note"] = "wall time of ixr_encode_run (statistics, keys, sort, dictionary, ids, DELTA / RLE / front-coding writers; incl. allocations, uploads, result download, sync)"
+    plan.destroy(); d_in.free(); d_dec.free()
     return res
 
 

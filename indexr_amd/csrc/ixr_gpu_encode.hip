@@ -50,8 +50,10 @@ struct EncPack {
     uint64_t s_segs;      // scratch: uint32 first row | RLE flag << 31 per segment, obj_count + 1 entries
     uint64_t s_pos;       // scratch: uint32 byte position of every segment
     // string packs only
-    uint64_t s_perm;      // scratch: uint32 row index per sort slot, obj_count rounded up to a power of two
-    uint64_t s_ent_row;   // scratch: uint32 a row holding entry e
+    uint64_t s_table;     // scratch: uint32 hash table of rows (first row seen with each distinct string), 2 * n2 slots
+    uint64_t s_rep;       // scratch: uint32 per row: the row that represents its string in the table
+    uint64_t s_rank;      // scratch: uint16 per row: dictionary id of the string a representative row holds
+    uint64_t s_perm;      // scratch: uint32 representative rows, sorted by their strings: slot e holds entry e (n2 slots)
     uint64_t s_pre;       // scratch: uint32 prefixLen per entry (front coding)
     uint64_t s_suf;       // scratch: uint32 suffixLen per entry
     uint64_t s_ent_off;   // scratch: uint32 offset of entry e in the dictionary body, obj_count + 1 entries
@@ -594,10 +596,10 @@ __global__ __launch_bounds__(kEncThreads) void k_enc_pack(const EncPack* __restr
 //   DictCodec.encodeStrings :379-433 (sorted set of the distinct strings, BytesUtil.compareBytes order: unsigned bytes,
 //   then length), DictStructUtil.compress :25-81 (entries plain as a StringsStruct, or front coded by
 //   DeltaCodec.encodeStrings :268-352 when there are >= 64 entries in >= 256 bytes), ids as RLE / bit-packing hybrid.
-// Steps: the offsets are checked; a bitonic sort orders the row indices by their strings (compare-exchange pairs spread
-// over the workgroup, one barrier per stage); neighbours that differ start a dictionary entry, the entry number of a slot is
-// the id of the row in it; entry lengths, common prefixes with the entry before and their running sums give every byte its
-// place; the writers are those of the numeric packs.
+// Steps: the offsets are checked; a hash table finds one representative row per distinct string; a bitonic sort orders the
+// representatives by their strings (compare-exchange pairs spread over the workgroup, one barrier per stage): slot e is
+// dictionary entry e, and a row's id is the slot of its representative; entry lengths, common prefixes with the entry
+// before and their running sums give every byte its place; the writers are those of the numeric packs.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr uint32_t kSortPad = 0xFFFFFFFFu;  // a slot past the last row: sorts after every string
 __device__ __forceinline__ int bytes_cmp(const uint8_t* a, int la, const uint8_t* b, int lb) {  // BytesUtil.compareBytes :7-19
@@ -662,15 +664,58 @@ __global__ __launch_bounds__(kEncThreads) void k_enc_str(const EncPack* __restri
     }
     __syncthreads();
     if (s_bad) { if (tid == 0) M.pack_size = IXR_ERR_INVALID_ARGUMENT; return; }
-    // sort
-    uint32_t* perm = (uint32_t*)(scratch + P.s_perm);
+    // distinct strings: every row goes into an open-addressing table keyed by a hash of its bytes; the first row to claim
+    // a slot represents its string, later rows with the same bytes take it as their representative
     uint32_t n2 = 2;
     while (n2 < (uint32_t)n) n2 <<= 1;
-    for (uint32_t i = tid; i < n2; i += kEncThreads) perm[i] = i < (uint32_t)n ? i : kSortPad;
+    uint32_t* table = (uint32_t*)(scratch + P.s_table);
+    uint32_t* rep = (uint32_t*)(scratch + P.s_rep);
+    const uint32_t tmask = 2 * n2 - 1;
+    for (uint32_t i = tid; i < 2 * n2; i += kEncThreads) table[i] = kSortPad;
     __syncthreads();
-    for (uint32_t k = 2; k <= n2; k <<= 1) {
+    for (int i = tid; i < n; i += kEncThreads) {
+        const int32_t a0 = off[i], len = off[i + 1] - a0;
+        const uint8_t* sp = S.body + a0;
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)(uint32_t)len;
+        int k = 0;
+        for (; k + 8 <= len; k += 8) {
+            uint64_t w;
+            __builtin_memcpy(&w, sp + k, 8);
+            h = (h ^ w) * 0xff51afd7ed558ccdull;
+            h ^= h >> 29;
+        }
+        uint64_t w = 0;
+        for (int q = 0; k + q < len; q++) w |= (uint64_t)sp[k + q] << (8 * q);
+        h = (h ^ w) * 0xc4ceb9fe1a85ec53ull;
+        h ^= h >> 32;
+        uint32_t slot = (uint32_t)h & tmask;
+        for (;;) {
+            uint32_t cur = atomicCAS(&table[slot], kSortPad, (uint32_t)i);
+            if (cur == kSortPad) cur = (uint32_t)i;
+            if (cur == (uint32_t)i || S.cmp(cur, (uint32_t)i) == 0) { rep[i] = cur; break; }
+            slot = (slot + 1) & tmask;  // the table has at least twice as many slots as rows: a free one comes up
+        }
+    }
+    __syncthreads();
+    // the representatives, compacted in row order, are what gets sorted
+    uint32_t* perm = (uint32_t*)(scratch + P.s_perm);
+    uint32_t carry = 0;
+    for (int base = 0; base < n; base += kEncThreads) {
+        const int i = base + tid;
+        const bool mine = i < n && rep[i] == (uint32_t)i;
+        uint32_t tot;
+        const uint32_t ex = wg_excl_scan(mine ? 1u : 0u, s_w, &tot);
+        if (mine) perm[carry + ex] = (uint32_t)i;
+        carry += tot;
+    }
+    const int ec = (int)carry;
+    uint32_t m2 = 2;
+    while (m2 < (uint32_t)ec) m2 <<= 1;
+    for (uint32_t i = ec + tid; i < m2; i += kEncThreads) perm[i] = kSortPad;
+    __syncthreads();
+    for (uint32_t k = 2; k <= m2; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < n2 / 2; t += kEncThreads) {
+            for (uint32_t t = tid; t < m2 / 2; t += kEncThreads) {
                 const uint32_t i = 2 * j * (t / j) + (t % j), l = i + j;
                 const uint32_t a = perm[i], b = perm[l];
                 const bool up = (i & k) == 0;
@@ -679,25 +724,13 @@ __global__ __launch_bounds__(kEncThreads) void k_enc_str(const EncPack* __restri
             __syncthreads();
         }
     }
-    // entries and ids
+    // slot e of the sorted representatives is dictionary entry e; a row's id is the entry of its representative
     uint16_t* ids = (uint16_t*)(scratch + P.s_ids);
-    uint32_t* ent_row = (uint32_t*)(scratch + P.s_ent_row);
-    uint32_t carry = 0;
-    for (int base = 0; base < n; base += kEncThreads) {
-        const int j = base + tid;
-        bool head = false;
-        uint32_t r = 0;
-        if (j < n) {
-            r = perm[j];
-            head = j == 0 || S.cmp(perm[j - 1], r) != 0;
-        }
-        uint32_t tot;
-        const uint32_t ex = wg_excl_scan(head ? 1u : 0u, s_w, &tot);
-        if (j < n) ids[r] = (uint16_t)(carry + ex + (head ? 1u : 0u) - 1u);
-        if (head) ent_row[carry + ex] = r;
-        carry += tot;
-    }
-    const int ec = (int)carry;
+    uint16_t* rank = (uint16_t*)(scratch + P.s_rank);
+    const uint32_t* ent_row = perm;
+    for (int e = tid; e < ec; e += kEncThreads) rank[perm[e]] = (uint16_t)e;
+    __syncthreads();
+    for (int i = tid; i < n; i += kEncThreads) ids[i] = rank[rep[i]];
     __syncthreads();
     // entry lengths, prefixes, running sums
     uint32_t* pre = (uint32_t*)(scratch + P.s_pre);
@@ -802,12 +835,14 @@ uint64_t layout_pack(EncPack& p, uint64_t off) {
     p.s_heads = take((nn + 1) * 4);
     p.s_segs = take((nn + 1) * 4);
     p.s_pos = take((nn + 1) * 4);
-    p.s_entries = p.s_perm = p.s_ent_row = p.s_pre = p.s_suf = p.s_ent_off = p.s_suf_off = 0;
+    p.s_entries = p.s_table = p.s_rep = p.s_rank = p.s_perm = p.s_pre = p.s_suf = p.s_ent_off = p.s_suf_off = 0;
     if (p.data_type == IXR_STRING) {
         uint64_t n2 = 2;
         while (n2 < nn) n2 <<= 1;
+        p.s_table = take(n2 * 8);
+        p.s_rep = take(nn * 4);
+        p.s_rank = take(nn * 2);
         p.s_perm = take(n2 * 4);
-        p.s_ent_row = take(nn * 4);
         p.s_pre = take(nn * 4);
         p.s_suf = take(nn * 4);
         p.s_ent_off = take((nn + 1) * 4);
