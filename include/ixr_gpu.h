@@ -250,12 +250,13 @@ int32_t ixr_compress_pack(int32_t data_type, int32_t is_indexed, int32_t obj_cou
 /* Upper bound for the compressed size (Codec.outputBufferSize, indexr-vlt-segment/.../codec/Codec.java:7-27). */
 int32_t ixr_compress_bound(int32_t obj_count, int32_t data_size);
 
-/* ---- write path on the device (numeric packs) -----------------------------------------------------------------------
- * The batch form of PackCompressor_VLT.compress (:23-96) for INT, LONG, FLOAT and DOUBLE packs: the same codec choice
- * (INT not indexed: dictionary when it has at most ceil(n * 0.2f) entries, else DELTA; everything else: dictionary) and
- * the same bytes as ixr_compress_pack, which is the reference's output.  String packs are encoded by ixr_compress_pack
- * on the host.
- *   d_data      device arena holding the decoded packs (raw little-endian arrays), src_off multiple of 16
+/* ---- write path on the device ---------------------------------------------------------------------------------------
+ * The batch form of PackCompressor_VLT.compress (:23-128): the same codec choice (INT not indexed: dictionary when it has
+ * at most ceil(n * 0.2f) entries, else DELTA; everything else: dictionary) and the same bytes as ixr_compress_pack, which
+ * is the reference's output.  A string pack whose dictionary form would not fit its slot reports
+ * IXR_ERR_BUFFER_OVERFLOW (the reference falls back to DELTA on strings there, :106-110; use ixr_compress_pack).
+ *   d_data      device arena holding the decoded packs (numbers: raw little-endian arrays; strings: StringsStruct, whose
+ *               offsets are checked on the device: IXR_ERR_INVALID_ARGUMENT in pack_size), src_off multiple of 16
  *   d_out       device arena; every pack gets a slot of ixr_compress_bound(obj_count, data_size) bytes at dst_off
  *               (multiple of 16); the compressed pack starts at dst_off
  *   descs[i]    pack_size receives the compressed size or a negative error, encode_type the CodecType id; min_value,
@@ -263,17 +264,17 @@ int32_t ixr_compress_bound(int32_t obj_count, int32_t data_size);
  *               DataPackNode: INT / LONG: min, max and the wrapping 64-bit sum; FLOAT / DOUBLE: the Math.min / Math.max
  *               fold (-0.0 < 0.0; with NaNs in the pack both are the last NaN) as Double.doubleToRawLongBits of the
  *               widened value, and the raw bits of the row-after-row sum in the column's precision, widened to double
- *               (a NaN sum is some NaN: which payload survives an addition is the hardware's choice)
+ *               (a NaN sum is some NaN: which payload survives an addition is the hardware's choice); string packs: 0
  * scratch_budget: device bytes the call may allocate for its working arrays (0 = 4 GiB); packs are processed in groups
  * that fit.  The call synchronises with `stream`.  Returns the number of packs that failed or a negative library error.
  */
 typedef struct ixr_encode_desc {
     uint64_t src_off;
     uint64_t dst_off;
-    int32_t  data_type;   /* IXR_INT ... IXR_DOUBLE */
+    int32_t  data_type;   /* IXR_INT ... IXR_STRING */
     int32_t  is_indexed;  /* the column's isIndexed flag */
     int32_t  obj_count;
-    int32_t  data_size;   /* obj_count * 4 or * 8 */
+    int32_t  data_size;   /* obj_count * 4 or * 8; strings: 4 * (obj_count + 1) + bytes */
     int32_t  pack_size;   /* out */
     int32_t  encode_type; /* out: IXR_ENC_DELTA or IXR_ENC_DICT_COMPRESS */
     int64_t  min_value;   /* out: dpn.minValue */

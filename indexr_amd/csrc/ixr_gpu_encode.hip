@@ -664,6 +664,12 @@ __global__ __launch_bounds__(kEncThreads) void k_enc_str(const EncPack* __restri
     }
     __syncthreads();
     if (s_bad) { if (tid == 0) M.pack_size = IXR_ERR_INVALID_ARGUMENT; return; }
+#ifdef IXR_ENC_TIMING
+    long long tk[6]; tk[0] = wall_clock64();
+#define TICK(k) tk[k] = wall_clock64()
+#else
+#define TICK(k)
+#endif
     // distinct strings: every row goes into an open-addressing table keyed by a hash of its bytes; the first row to claim
     // a slot represents its string, later rows with the same bytes take it as their representative
     uint32_t n2 = 2;
@@ -697,6 +703,7 @@ __global__ __launch_bounds__(kEncThreads) void k_enc_str(const EncPack* __restri
         }
     }
     __syncthreads();
+    TICK(1);
     // the representatives, compacted in row order, are what gets sorted
     uint32_t* perm = (uint32_t*)(scratch + P.s_perm);
     uint32_t carry = 0;
@@ -724,6 +731,7 @@ __global__ __launch_bounds__(kEncThreads) void k_enc_str(const EncPack* __restri
             __syncthreads();
         }
     }
+    TICK(2);
     // slot e of the sorted representatives is dictionary entry e; a row's id is the entry of its representative
     uint16_t* ids = (uint16_t*)(scratch + P.s_ids);
     uint16_t* rank = (uint16_t*)(scratch + P.s_rank);
@@ -763,6 +771,7 @@ __global__ __launch_bounds__(kEncThreads) void k_enc_str(const EncPack* __restri
         suf_carry += tot;
     }
     __syncthreads();
+    TICK(3);
     const uint32_t body_bytes = len_carry, suf_bytes = suf_carry;
     const uint64_t dict_size = 4ull * ((uint32_t)ec + 1) + body_bytes;
     const bool compressed = ec >= 64 && dict_size >= 256;  // DictStructUtil.java:26-27
@@ -801,9 +810,14 @@ __global__ __launch_bounds__(kEncThreads) void k_enc_str(const EncPack* __restri
         esz = 4u + d1 + d2 + suf_bytes;
     }
     __syncthreads();
+    TICK(4);
     const int bw = bit_width64((uint64_t)(uint32_t)(ec - 1));
     const uint32_t rsz = wg_rle_encode(ids, n, bw, dst + 9 + esz, cap - 9 - esz, (uint16_t*)(scratch + P.s_run_of), (uint32_t*)(scratch + P.s_heads),
                                        (uint16_t*)(scratch + P.s_seg_of), (uint32_t*)(scratch + P.s_segs), (uint32_t*)(scratch + P.s_pos), s_w);
+#ifdef IXR_ENC_TIMING
+    TICK(5);
+    if (tid == 0) { M.min_value = ((tk[1] - tk[0]) << 32) | (tk[2] - tk[1]); M.max_value = ((tk[3] - tk[2]) << 32) | (tk[4] - tk[3]); M.sum = tk[5] - tk[4]; }
+#endif
     if (tid == 0) { M.entry_count = ec; M.use_dict = 1; M.pack_size = rsz ? (int32_t)(9u + esz + rsz) : kEncOverflow; M.encode_type = IXR_ENC_DICT_COMPRESS; }
 }
 
