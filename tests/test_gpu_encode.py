@@ -207,3 +207,68 @@ def test_gpu_encoder_output_decodes_on_the_gpu():
         if plan is not None:
             plan.destroy()
         d_data.free(); d_cmp.free(); d_back.free()
+
+
+def random_pack(rng):
+    """one pack of random shape: type, row count, value domain and run structure all drawn at random"""
+    dt = int(rng.choice([O.INT, O.LONG, O.FLOAT, O.DOUBLE, O.STRING]))
+    n = int(rng.choice([rng.integers(1, 40), rng.integers(40, 700), rng.integers(700, 5000)]))
+    card = int(rng.choice([1, 2, 3, 17, 63, 64, 65, 300, 5000]))
+    run = int(rng.choice([1, 1, 2, 7, 8, 9, 40]))
+    base = rng.integers(0, card, n // run + 1)
+    pick = np.repeat(base, rng.integers(1, run + 1, len(base)) if run > 1 else 1)
+    pick = np.resize(pick, n)
+    idx = bool(rng.integers(0, 2))
+    if dt == O.INT:
+        dom = rng.integers(-2**31, 2**31, card) if rng.random() < 0.5 else rng.integers(-50, 50, card) * int(rng.integers(1, 1000))
+        return dt, idx, dom[pick].astype("<i4")
+    if dt == O.LONG:
+        dom = rng.integers(-2**63, 2**63, card, dtype=np.int64) if rng.random() < 0.5 else np.cumsum(rng.integers(0, 10**6, card))
+        return dt, idx, dom[pick].astype("<i8")
+    if dt == O.FLOAT:
+        dom = rng.standard_normal(card).astype("<f4")
+        if rng.random() < 0.3:
+            dom[: min(card, 4)] = np.array([0.0, -0.0, np.nan, np.inf], dtype="<f4")[: min(card, 4)]
+        return dt, idx, dom[pick]
+    if dt == O.DOUBLE:
+        dom = (rng.integers(-10**6, 10**6, card) / 8).astype("<f8")
+        if rng.random() < 0.3:
+            dom[: min(card, 4)] = np.array([0.0, -0.0, np.nan, -np.inf], dtype="<f8")[: min(card, 4)]
+        return dt, idx, dom[pick]
+    alphabet = rng.integers(0, 256, int(rng.choice([2, 5, 256]))).astype(np.uint8)
+    dom = [bytes(alphabet[rng.integers(0, len(alphabet), rng.integers(0, int(rng.choice([3, 12, 90]))))]) for _ in range(card)]
+    return dt, idx, [dom[i] for i in pick]
+
+
+@pytest.mark.gpu
+def test_gpu_encoder_on_random_packs():
+    rng = np.random.default_rng(987654321)
+    cases = [random_pack(rng) for _ in range(1500)]
+    descs, parts, src, dst = [], [], 0, 0
+    for dt, idx, rows in cases:
+        data = O.rows_to_bytes(rows, dt)
+        parts.append(data)
+        pad = -len(data) % 16
+        parts.append(np.zeros(pad, dtype=np.uint8))
+        descs.append(L.EncodeDesc(src, dst, dt, int(idx), len(rows), len(data), 0, 0, 0, 0, 0))
+        src += len(data) + pad
+        dst += (L.lib.ixr_compress_bound(len(rows), len(data)) + 15) & ~15
+    arena = np.concatenate(parts)
+    d_data, d_out = L.DeviceBuffer(0, len(arena)), L.DeviceBuffer(0, dst)
+    try:
+        d_data.upload(arena)
+        d_out.upload(np.full(dst, 0xCD, dtype=np.uint8))
+        arr, bad = L.encode_run(descs, d_data.ptr, len(arena), d_out.ptr, dst)
+        assert bad == 0
+        host = d_out.download()
+        for k, ((dt, idx, rows), a) in enumerate(zip(cases, arr)):
+            want, et = O.compress_pack(O.rows_to_bytes(rows, dt), dt, len(rows), idx)
+            got = host[a.dst_off:a.dst_off + a.pack_size]
+            assert a.encode_type == et and a.pack_size == len(want) and np.array_equal(got, want), (k, dt, idx, len(rows), a.pack_size, len(want))
+            if dt != O.STRING:
+                mn, mx, sm = O.pack_stats(O.rows_to_bytes(rows, dt), dt, len(rows))
+                assert (a.min_value, a.max_value) == (mn, mx), (k, dt)
+                assert a.sum == sm or (dt in (O.FLOAT, O.DOUBLE) and np.isnan(as_double(sm)) and np.isnan(as_double(a.sum))), (k, dt)
+    finally:
+        d_data.free()
+        d_out.free()
