@@ -1272,55 +1272,84 @@ __global__ __launch_bounds__(64) void k_front_combine(const DevPack* __restrict_
     }
 }
 
+// Four blocks per wave: 16 lanes per block, a lane owns FOUR neighbouring byte columns as one dword, so a step moves four
+// strings of up to 64 bytes with one load and one store per lane.  The blocks' lengths and offsets are staged in LDS (one
+// 16-byte record per string, read back as a broadcast within each group of 16 lanes).  Columns 64.. take further rounds.
+__device__ __forceinline__ uint32_t byte_mask(uint32_t x) { return x >= 4 ? 0xFFFFFFFFu : ((1u << (8 * x)) - 1u); }
 __global__ __launch_bounds__(256) void k_front_decode(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                       const PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                       uint8_t* __restrict__ out, uint8_t* __restrict__ scratch,
                                                       const uint8_t* __restrict__ ro, int use_ds) {
+    __shared__ uint4 s_meta[4][4 * kFrontBlock];  // per wave: (prefixLen, length, body offset, suffix position - prefixLen)
     uint32_t bx, by;
     pack_block_remap(bx, by);
     const int pi = list[by];
     const DevPack& P = packs[pi];
     FrontCtx f;
     if (!front_ctx(f, P, metas[pi], in, out, scratch, ro, use_ds, true)) return;
-    const int lane = threadIdx.x & 63;
-    constexpr int kB = IXR_FRONT_BATCH;  // strings per step
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(bx * 4 + (threadIdx.x >> 6)), nwaves = gridDim.x * 4;
-    for (uint32_t b = wave; b < f.nblk; b += nwaves) {
-        const uint32_t i0 = b * kFrontBlock;
-        const uint32_t cnt = min((uint32_t)kFrontBlock, f.ec - i0);
-        // lane k holds the lengths and offsets of the block's string k; the loop below broadcasts them with readlane
-        const uint32_t ii = min(i0 + lane, f.ec - 1);
-        const uint32_t mp = (uint32_t)f.pre[ii], mso = f.sufoff[ii], mo = f.doff[ii];
-        const uint32_t mlen = (uint32_t)lane < cnt ? mp + (uint32_t)f.suf[ii] : 0u;  // length 0: no column takes part
-        const uint32_t msp = mso - mp;  // source position of column j is msp + j (for columns inside the suffix)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+    constexpr int kB = IXR_FRONT_BATCH;  // strings per step and group
+    const uint32_t wave = bx * 4 + wv, nwaves = gridDim.x * 4;
+    const uint32_t ntask = (f.nblk + 3) / 4;
+    uint4* meta = s_meta[wv];
+    for (uint32_t task = wave; task < ntask; task += nwaves) {
+        const uint32_t b0 = task * 4;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the round before has read its records
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t i = (b0 + q) * kFrontBlock + lane;
+            const uint32_t ii = min(i, f.ec - 1);
+            const uint32_t p = (uint32_t)f.pre[ii];
+            const uint32_t len = i < f.ec ? p + (uint32_t)f.suf[ii] : 0u;  // length 0: no column takes part
+            meta[q * kFrontBlock + lane] = make_uint4(p, len, f.doff[ii], f.sufoff[ii] - p);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t b = b0 + g;
+        const uint4* mine = meta + g * kFrontBlock;
         for (uint32_t col0 = 0; col0 < f.stride; col0 += 64) {
-            const uint32_t j = col0 + lane;
-            uint32_t cur = f.sum[(size_t)b * f.stride + j];
-            // strings that end before our columns neither read nor write here: skip batches made of them only
-            const uint64_t reach = __ballot(mlen > col0);
-            for (uint32_t k0 = 0; k0 < cnt; k0 += kB) {
-                if (((reach >> k0) & ((1ull << kB) - 1ull)) == 0) continue;
-                // kB strings per step: all suffix loads are issued before the first byte is consumed
-                uint32_t p[kB], len[kB], o[kB], t[kB];
+            const uint32_t j0 = col0 + 4 * c;
+            uint32_t cur = 0;
+            if (b < f.nblk) {  // the four columns' bytes before the block (one uint16 each)
+                const uint2 st = *(const uint2*)(f.sum + (size_t)b * f.stride + j0);
+                cur = (st.x & 0xFFu) | ((st.x >> 8) & 0xFF00u) | ((st.y & 0xFFu) << 16) | ((st.y << 8) & 0xFF000000u);
+            }
+            for (uint32_t k0 = 0; k0 < (uint32_t)kFrontBlock; k0 += kB) {
+                uint4 m[kB];
+                bool reach = false;
 #pragma unroll
                 for (int q = 0; q < kB; q++) {
-                    const uint32_t k = k0 + q;  // <= 63; lanes >= cnt hold length 0
-                    p[q] = __builtin_amdgcn_readlane(mp, k);
-                    len[q] = __builtin_amdgcn_readlane(mlen, k);
-                    o[q] = __builtin_amdgcn_readlane(mo, k);
-                    const uint32_t so = __builtin_amdgcn_readlane(mso, k), sp = __builtin_amdgcn_readlane(msp, k);
-                    // unconditional, clamped load (so + 0 is always readable: suffix bytes are followed by the id stream)
-                    t[q] = f.sfx[(j >= p[q] && j < len[q]) ? sp + j : so];
+                    m[q] = mine[k0 + q];
+                    reach |= m[q].y > j0;
                 }
-                // keep the loads together: without this the compiler sinks one of them into a conditional block behind a
-                // full wait, which costs a second memory round trip per batch
+                if (!__any(reach)) continue;  // strings that end before these columns neither read nor write here
+                uint32_t t[kB];
+#pragma unroll
+                for (int q = 0; q < kB; q++) {
+                    // unconditional, clamped load: where no column takes a new byte read the string's first suffix byte
+                    // position (always readable: the suffix bytes are followed by the id stream and the input slack)
+                    const bool fresh = j0 + 4 > m[q].x && j0 < m[q].y;
+                    const int32_t at = (int32_t)(m[q].w + (fresh ? j0 : m[q].x));  // may lie up to 3 bytes before the suffix: pack header
+                    __builtin_memcpy(&t[q], f.sfx + at, 4);
+                }
 #pragma unroll
                 for (int q = 0; q < kB; q += 8)
                     asm volatile("" : "+v"(t[q]), "+v"(t[q + 1]), "+v"(t[q + 2]), "+v"(t[q + 3]), "+v"(t[q + 4]), "+v"(t[q + 5]), "+v"(t[q + 6]), "+v"(t[q + 7]));
 #pragma unroll
                 for (int q = 0; q < kB; q++) {
-                    cur = (j >= p[q] && j < len[q]) ? t[q] : cur;
-                    if (j < len[q]) f.body[o[q] + j] = (uint8_t)cur;
+                    const uint32_t p = m[q].x, len = m[q].y;
+                    const uint32_t lo = p > j0 ? min(p - j0, 4u) : 0u, hi = len > j0 ? min(len - j0, 4u) : 0u;
+                    const uint32_t take = byte_mask(hi) & ~byte_mask(lo);  // columns inside the suffix
+                    cur = (cur & ~take) | (t[q] & take);
+                    uint8_t* dst = f.body + m[q].z + j0;
+                    if (hi == 4) __builtin_memcpy(dst, &cur, 4);
+                    else if (hi) {
+                        dst[0] = (uint8_t)cur;
+                        if (hi > 1) dst[1] = (uint8_t)(cur >> 8);
+                        if (hi > 2) dst[2] = (uint8_t)(cur >> 16);
+                    }
                 }
             }
         }
@@ -2200,7 +2229,7 @@ void launch_front_combine(const LaunchCtx& c, const int* list, int count, int us
 }
 void launch_front_decode(const LaunchCtx& c, const int* list, int count, int use_ds) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_front_decode, dim3(64, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch,
+    hipLaunchKernelGGL(k_front_decode, dim3(16, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch,
                        (const uint8_t*)c.scratch, use_ds);
 }
 void launch_str_index(const LaunchCtx& c, const int* list, int count) {
