@@ -114,6 +114,10 @@ void      ixr_plan_totals(const ixr_plan* plan, uint64_t* in_bytes, uint64_t* ou
 /* Names and accumulated device time (ms, measured with HIP events on `stream` when profiling was enabled with
  * ixr_plan_set_profiling) of the kernels of the last run; returns the number of entries written (<= cap). */
 void      ixr_plan_set_profiling(ixr_plan* plan, int32_t enabled);
+/* A run keeps two streams busy: the numeric kernels of a group go to a stream of the plan's own beside the string kernels
+ * on the caller's stream.  enabled = 0 keeps everything on the caller's stream, one kernel after the other (the default is
+ * 1); a kernel's event time then is its time alone on the device, which is what kernel tuning wants to look at. */
+void      ixr_plan_set_overlap(ixr_plan* plan, int32_t enabled);
 int32_t   ixr_plan_kernel_times(ixr_plan* plan, const char** names, float* ms, int32_t* launches, int32_t cap);
 /* Algorithmic bytes attributed to each kernel of the last run (same order and names as ixr_plan_kernel_times, valid after
  * ixr_plan_status): every compressed byte of a pack is attributed to the kernel that consumes it and every decoded byte

@@ -177,6 +177,7 @@ struct ixr_plan {
     uint64_t in_need = 0, out_need = 0;
     uint64_t tot_in = 0, tot_out = 0, tot_rows = 0;
     bool profiling = false;
+    bool overlap = true;  // numeric kernels on the auxiliary stream beside the string kernels (ixr_plan_set_overlap)
     std::vector<TimedLaunch> timed;       // launches of the last run (profiling only)
     std::vector<hipEvent_t> event_pool;   // reused across runs
     size_t event_used = 0;
@@ -355,6 +356,9 @@ extern "C" void ixr_plan_totals(const ixr_plan* p, uint64_t* in_bytes, uint64_t*
 extern "C" void ixr_plan_set_profiling(ixr_plan* p, int32_t enabled) {
     if (p) p->profiling = enabled != 0;
 }
+extern "C" void ixr_plan_set_overlap(ixr_plan* p, int32_t enabled) {
+    if (p) p->overlap = enabled != 0;
+}
 
 namespace {
 // Brackets one launch with events when profiling is on.
@@ -429,7 +433,7 @@ extern "C" int32_t ixr_plan_run(ixr_plan* pl, const void* d_in, uint64_t in_byte
     const int* L = pl->d_lists;
     run_parse_all(pl, T, c);
     for (const Group& g : pl->groups) {
-        const bool fork = g.cnt[L_STR] > 0 && (g.cnt[L_N32] + g.cnt[L_N64] + g.cnt[L_RAW]) > 0;
+        const bool fork = pl->overlap && g.cnt[L_STR] > 0 && (g.cnt[L_N32] + g.cnt[L_N64] + g.cnt[L_RAW]) > 0;
         LaunchCtx& cn = fork ? cb : c;  // numeric kernels: on the auxiliary stream when there is string work to overlap
         Timer& TN = fork ? TB : T;
         if (fork) {

@@ -1395,16 +1395,21 @@ __global__ __launch_bounds__(256) void k_row_scan(const DevPack* __restrict__ pa
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_str_index: string dictionary packs, one workgroup of 16 waves per pack.  Per round each wave expands one tile of
-// kRleTile ids, looks up the rows' dictionary slices and scans the row lengths; the workgroup chains the 16 tiles and the
+// k_str_index: string dictionary packs, one workgroup of 4 waves per pack (a small workgroup finds room on a compute unit
+// while the numeric kernels of the other stream keep the device busy; 16 waves waited).  Per round each wave expands one tile of
+// kRleTile ids, looks up the rows' dictionary slices and scans the row lengths; the workgroup chains the tiles and the
 // rounds with a running total.  Writes the output index (offset[0] = 0, offset[i+1] = offset[i] + len[i];
 // StringsStruct.Builder, StringsStruct.java:120-158) and each row's slice start into scratch, checks that the body fits,
 // zero-fills what the body leaves of dpn.dataSize.  (DictStruct.decodeStrings, DictStruct.java:97-110.)
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_str_index(const DevPack* __restrict__ packs, const int* __restrict__ list,
+#ifndef IXR_STR_INDEX_WAVES
+#define IXR_STR_INDEX_WAVES 4
+#endif
+constexpr int kStrIndexWaves = IXR_STR_INDEX_WAVES;
+__global__ __launch_bounds__(kStrIndexWaves * 64) void k_str_index(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                     PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ scratch) {
-    constexpr int kWaves = 16;
+    constexpr int kWaves = kStrIndexWaves;
     __shared__ uint16_t s_ids[kWaves][kRleTile];
     __shared__ __align__(16) uint8_t s_win[kWaves][kWinAlloc];
     __shared__ uint32_t s_wsum[2][kWaves];
@@ -1489,7 +1494,7 @@ __global__ __launch_bounds__(1024) void k_str_index(const DevPack* __restrict__ 
     // A body shorter than dpn.dataSize promises leaves a tail: the reference decodes into a zero-filled direct buffer
     // (PackCompressor_VLT.java:133, ByteBufferUtil.java:31-36), so the tail reads as zeros.
     uint8_t* tail = out + P.out_off + 4ull * (n + 1) + tot64;
-    for (uint64_t i = tid; i < body_cap - tot64; i += 1024) tail[i] = 0;
+    for (uint64_t i = tid; i < body_cap - tot64; i += kWaves * 64) tail[i] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2234,7 +2239,7 @@ void launch_front_decode(const LaunchCtx& c, const int* list, int count, int use
 }
 void launch_str_index(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_str_index, dim3(count), dim3(1024), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+    hipLaunchKernelGGL(k_str_index, dim3(count), dim3(kStrIndexWaves * 64), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
 }
 void launch_row_scan(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;

@@ -101,6 +101,7 @@ _sig = {
     "ixr_plan_status": (_i32, [_vp, C.POINTER(_i32), _vp]),
     "ixr_plan_totals": (None, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
     "ixr_plan_set_profiling": (None, [_vp, _i32]),
+    "ixr_plan_set_overlap": (None, [_vp, _i32]),
     "ixr_plan_kernel_times": (_i32, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(_i32), _i32]),
     "ixr_plan_kernel_bytes": (_i32, [_vp, C.POINTER(_u64), _i32]),
     "ixr_plan_run_dict_structs": (_i32, [_vp, _vp, _u64, _vp, _u64, C.POINTER(_u64), _vp]),
@@ -264,6 +265,9 @@ class Plan:
 
     def set_profiling(self, on):
         lib.ixr_plan_set_profiling(self.handle, int(on))
+
+    def set_overlap(self, on):
+        lib.ixr_plan_set_overlap(self.handle, int(on))
 
     def kernel_times(self):
         cap = 64
