@@ -1,13 +1,14 @@
-// ixr_gpu_encode.hip -- numeric pack encoder on the device: the batch form of the write path
-//   PackCompressor_VLT.compress           indexr-vlt-segment/.../segment/pack/PackCompressor_VLT.java:23-128 (INT ... DOUBLE)
+// ixr_gpu_encode.hip -- pack encoder on the device: the batch form of the write path
+//   DataPackCreator_VLT.from              indexr-vlt-segment/.../segment/pack/DataPackCreator_VLT.java:21-213 (dpn statistics)
+//   PackCompressor_VLT.compress           indexr-vlt-segment/.../segment/pack/PackCompressor_VLT.java:23-128
 //   DictCompressCodec.encode*             .../codec/dict/DictCompressCodec.java:40-69
-//   DictCodec.encode* (sorted dictionary) .../codec/dict/DictCodec.java:79-131, 154-206, 229-281, 304-356
+//   DictCodec.encode* (sorted dictionary) .../codec/dict/DictCodec.java:79-131, 154-206, 229-281, 304-356, 379-433
 //   DictStructUtil.compress               .../codec/dict/DictStructUtil.java:25-81
-//   DeltaCodec.encodeInts / encodeLongs   .../codec/delta/DeltaCodec.java:40-97, 144-201
+//   DeltaCodec.encodeInts / encodeLongs   .../codec/delta/DeltaCodec.java:40-97, 144-201; encodeStrings :268-352
 //   RLEPackingHybridCodec.encodeInts      .../codec/rle/RLEPackingHybridCodec.java:38-94
 // The bytes it writes are those of the host encoder in ixr_encode.cpp (and of the reference), pack for pack.
 //
-// Per group of packs:
+// Per group of packs, numeric packs (INT, LONG, FLOAT, DOUBLE):
 //   k_enc_stats  dpn.minValue / maxValue / sum (DataPackCreator_VLT.java:21-163)
 //   k_enc_keys   rows -> unsigned keys whose order is the dictionary's order (signed ints; Float/Double.compare with the
 //                NaNs collapsed); notes the first NaN row of a pack (its bits become the NaN entry)
@@ -17,6 +18,8 @@
 //   k_enc_pack   one workgroup per pack: DICT_COMPRESS (entries plain or DELTA, ids RLE / bit-packing hybrid) or DELTA
 //                over the rows.  Sizes first (workgroup scans over blocks / runs / segments), then every block, header
 //                and group of 8 values is written at its final position independently.
+// String packs:
+//   k_enc_str    one workgroup per pack, everything from the StringsStruct to the DICT_COMPRESS pack (see the kernel)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -301,10 +304,12 @@ template <typename T> __device__ __forceinline__ int plain_search(const T* e, in
     return -1;
 }
 
+constexpr int kDictSamples = 2048;  // dictionary keys kept in LDS for the first level of the id search
 template <typename U>
 __global__ __launch_bounds__(kEncThreads) void k_enc_dict(const EncPack* __restrict__ packs, const int* __restrict__ list, EncMeta* __restrict__ metas,
                                                           const uint8_t* __restrict__ data, const U* __restrict__ sorted, uint8_t* __restrict__ scratch) {
     __shared__ uint32_t s_w[kEncWaves + 1];
+    __shared__ U s_keys[kDictSamples];
     const int pi = list[blockIdx.x];
     const EncPack P = packs[pi];
     EncMeta& M = metas[pi];
@@ -339,18 +344,49 @@ __global__ __launch_bounds__(kEncThreads) void k_enc_dict(const EncPack* __restr
     if (tid == 0) { M.entry_count = ec; M.use_dict = use_dict ? 1 : 0; }
     if (!use_dict) return;
     __syncthreads();  // the entries written above are read below by other threads of this workgroup
+    // Every row's value is in the dictionary, at one place: any search finds the id the reference's binarySearch finds.
+    // Two levels: every stride-th entry's key is kept in LDS, the rest of the search touches at most log2(stride) entries
+    // in memory.  Only zeros and NaNs of float columns depend on the reference's probe order (a zero equals the zero of
+    // the other sign, a NaN "equals" the first entry probed): those rows take the plain search.
+    auto key_of = [&](U bits) -> U {
+        if (!fp) return bits ^ sign;
+        bool nan;
+        if constexpr (sizeof(U) == 4) return fkey(bits, &nan);
+        else return dkey(bits, &nan);
+    };
+    const int stride = (ec + kDictSamples - 1) / kDictSamples;
+    const int ns = (ec + stride - 1) / stride;
+    for (int j = tid; j < ns; j += kEncThreads) s_keys[j] = key_of(ent[(size_t)j * stride]);
+    __syncthreads();
     uint16_t* ids = (uint16_t*)(scratch + P.s_ids);
     bool bad = false;
     for (int i = tid; i < n; i += kEncThreads) {
         const U b = rows[i];
         int id;
-        if (P.data_type == IXR_INT || P.data_type == IXR_LONG) {
-            using S = typename std::make_signed<U>::type;
-            id = plain_search<S>((const S*)ent, ec, (S)b);
-        } else if constexpr (sizeof(U) == 4) {
-            id = plain_search<float>((const float*)ent, ec, __uint_as_float(b));
+        bool special = false;
+        if (fp) {
+            const U mag = b & ~sign;
+            special = mag == 0 || (sizeof(U) == 4 ? mag > (U)0x7f800000u : mag > (U)0x7ff0000000000000ull);
+        }
+        if (special) {
+            if constexpr (sizeof(U) == 4) id = plain_search<float>((const float*)ent, ec, __uint_as_float(b));
+            else id = plain_search<double>((const double*)ent, ec, __longlong_as_double((long long)b));
         } else {
-            id = plain_search<double>((const double*)ent, ec, __longlong_as_double((long long)b));
+            const U k = key_of(b);
+            int lo = 0, hi = ns - 1;  // last sample <= k
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (s_keys[mid] <= k) lo = mid; else hi = mid - 1;
+            }
+            int a = lo * stride, z = min(a + stride, ec) - 1;
+            id = -1;
+            while (a <= z) {
+                const int mid = (a + z) >> 1;
+                const U v = key_of(ent[mid]);
+                if (v < k) a = mid + 1;
+                else if (v > k) z = mid - 1;
+                else { id = mid; break; }
+            }
         }
         if (id < 0) { bad = true; id = 0; }
         ids[i] = (uint16_t)id;
