@@ -805,6 +805,7 @@ extern "C" int32_t ixr_plan_run_filter(ixr_plan* pl, const void* d_in, uint64_t 
         d.result = IXR_ERR_BUG; d.from = d.to = d.n_match = d.pad = 0;
         // matched ids: at most one per key; LIKE can match every dictionary entry, and a pack has at most objCount of them
         n_keys += f.op == IXR_FILTER_LIKE ? (uint64_t)std::max(pl->descs[(size_t)i].obj_count, 1) : (uint64_t)f.n_values;
+        if (n_keys > 0xFFFFFFFFull) return fail(IXR_ERR_INVALID_ARGUMENT, "filter %d: more than 2^32 key slots in one call; split the plan", i);
     }
     HIP_TRY(hipSetDevice(pl->device), return IXR_ERR_HIP);
     hipStream_t st = (hipStream_t)stream;

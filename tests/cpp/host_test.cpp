@@ -2,12 +2,14 @@
 // tests do (DataPackTest.java:30-65,106-169; DPSegmentTest / StorageColumn.pack loop), against libixrgpu.
 //   host_test --cpu <tmpdir>   everything that needs no device: geometry, DPN records, creators, host compress,
 //                              segment file write/read, CPU scan of the file with the oracle
-//   host_test --gpu <tmpdir>   the decode path on the device: DataPack life cycle, DictStruct, batch, segment scan, errors
+//   host_test --gpu <tmpdir>   the decode path on the device: DataPack life cycle, DictStruct, batch, segment scan, errors,
+//                              pack filters (PackExtIndex) and the batch encoder
 // The CPU oracle (oracle/) is linked here as the checker only.
 #include <cinttypes>
 #include <cstdio>
 #include <limits>
 
+#include "ixr_ext.hpp"
 #include "ixr_segment_file.hpp"
 #include "ixr_synth.h"
 extern "C" {
@@ -275,6 +277,123 @@ static void test_segment_scan_gpu(VersionAdapter& va, const std::string& dir) {
     CHECK(same(one.data(), c.source[3][15]) && one.objCount() == 16960);
 }
 
+// PackExtIndex through the batch wrapper: a pack gets ExtIndex_DictBits or ExtIndex_SimpleBits as VersionAdapter_VLT.createExtIndex
+// chooses; every bitmap is compared with the oracle's restatement of the class that applies.
+static void check_bitmap(const BitMap& got, const DataPack& p, uint8_t dt, const PackPredicate& pr) {
+    std::vector<uint64_t> want(1024);
+    std::vector<uint8_t> sv;
+    const bool str = !pr.strValues.empty();
+    if (str) {
+        int32_t off = 0;
+        for (size_t i = 0; i <= pr.strValues.size(); i++) {
+            const uint8_t* q = (const uint8_t*)&off;
+            sv.insert(sv.end(), q, q + 4);
+            if (i < pr.strValues.size()) off += (int32_t)pr.strValues[i].size();
+        }
+        for (auto& s : pr.strValues) sv.insert(sv.end(), s.begin(), s.end());
+        sv.push_back(0);
+    }
+    const int nv = str ? (int)pr.strValues.size() : (int)pr.numValues.size();
+    int r;
+    if (p.dpn().isDictEncoded())
+        r = ixo_filter(dt, p.dpn().encodeType, p.objCount(), p.cmpData().address(), (int)p.cmpData().size(), pr.op, nv,
+                       str ? nullptr : pr.numValues.data(), str ? sv.data() : nullptr, want.data());
+    else
+        r = ixo_scan_filter(dt, p.objCount(), p.data().address(), (int)p.data().size(), pr.op, nv, str ? nullptr : pr.numValues.data(),
+                            str ? sv.data() : nullptr, want.data());
+    CHECK(r == (int)got.kind);
+    if (r == BitMap::SOME) CHECK(got.words.size() == 1024 && std::memcmp(got.words.data(), want.data(), 8192) == 0);
+    int card = 0;
+    for (int i = 0; i < p.objCount(); i++) card += got.get(i);
+    CHECK(card == got.cardinality());
+}
+static void test_ext_index_gpu(VersionAdapter& va) {
+    std::vector<int32_t> cat(30000), seq(30000);
+    for (size_t i = 0; i < cat.size(); i++) { cat[i] = (int32_t)((i * 2654435761u) % 97) * 13 - 300; seq[i] = (int32_t)(i * 3 + (i * 7919u) % 3); }
+    std::vector<std::string> os;
+    const char* names[] = {"windows", "mac", "linux", "android", "win98", "", "w%n"};
+    for (int i = 0; i < 20000; i++) os.push_back(names[(i * 31 + i / 7) % 7]);
+    DataPack pc = DataPack::fromInts(cat.data(), (int)cat.size()), ps = DataPack::fromInts(seq.data(), (int)seq.size()), po = DataPack::fromStrings(os);
+    pc.compress(va, VERSION, ColumnType::INT, false);
+    ps.compress(va, VERSION, ColumnType::INT, false);
+    po.compress(va, VERSION, ColumnType::STRING, false);
+    CHECK(pc.dpn().isDictEncoded() && !ps.dpn().isDictEncoded() && po.dpn().isDictEncoded());
+    struct Case { DataPack* p; uint8_t dt; PackPredicate pr; };
+    std::vector<Case> cases = {
+        {&pc, ColumnType::INT, PackPredicate::equal((int64_t)(13 * 5 - 300))}, {&pc, ColumnType::INT, PackPredicate::equal((int64_t)1)},
+        {&pc, ColumnType::INT, PackPredicate::in({-300, 2, 13 * 96 - 300})},  {&pc, ColumnType::INT, PackPredicate::greater((int64_t)400, true)},
+        {&pc, ColumnType::INT, PackPredicate::greater((int64_t)-1000, false)}, {&pc, ColumnType::INT, PackPredicate::between(0, 500)},
+        {&ps, ColumnType::INT, PackPredicate::equal((int64_t)seq[777])},       {&ps, ColumnType::INT, PackPredicate::equal((int64_t)-5)},
+        {&ps, ColumnType::INT, PackPredicate::in({seq[1], seq[29999], 1 << 30})}, {&ps, ColumnType::INT, PackPredicate::greater((int64_t)45000, false)},
+        {&ps, ColumnType::INT, PackPredicate::between(1000, 2000)},          {&ps, ColumnType::INT, PackPredicate::greater((int64_t)-1, true)},
+        {&po, ColumnType::STRING, PackPredicate::equal(std::string("mac"))},   {&po, ColumnType::STRING, PackPredicate::equal(std::string("macos"))},
+        {&po, ColumnType::STRING, PackPredicate::in({"linux", "", "nope"})},  {&po, ColumnType::STRING, PackPredicate::greater(std::string("linux"), false)},
+        {&po, ColumnType::STRING, PackPredicate::between("a", "m")},           {&po, ColumnType::STRING, PackPredicate::like("win%")},
+        {&po, ColumnType::STRING, PackPredicate::like("w\\%n")},              {&po, ColumnType::STRING, PackPredicate::like("%n%d%")},
+    };
+    PackExtIndexBatch b(0);
+    for (auto& c : cases) b.add(c.dt, c.p->dpn(), c.p->cmpData(), c.pr);
+    b.run();
+    int kinds[3] = {0, 0, 0};
+    for (size_t i = 0; i < cases.size(); i++) {
+        check_bitmap(b.result((int)i), *cases[i].p, cases[i].dt, cases[i].pr);
+        kinds[b.result((int)i).kind]++;
+    }
+    CHECK(kinds[0] > 0 && kinds[1] > 0 && kinds[2] > 0);
+    CHECK(b.result(17).cardinality() > 0 && b.result(18).cardinality() > 0);  // 'win%': windows, win98; 'w\%n': the literal w%n
+    PackExtIndexBatch bad(0);
+    bad.add(ColumnType::INT, pc.dpn(), pc.cmpData(), PackPredicate::like("1%"));
+    CHECK_THROWS(bad.run(), "is illegal in LIKE");
+    PackExtIndexBatch bad2(0);
+    bad2.add(ColumnType::INT, ps.dpn(), ps.cmpData(), PackPredicate::like("1%"));
+    CHECK_THROWS(bad2.run(), "is illegal in LIKE");
+}
+// DataPackCreator_VLT.from + compress for a batch of packs on the device: same bytes and dpn as pack-by-pack on the host
+static void test_encode_batch_gpu(VersionAdapter& va) {
+    std::vector<int32_t> iv(50000), iw(50000);
+    std::vector<int64_t> lv(40000);
+    std::vector<float> fv(30000);
+    std::vector<double> dv(65536);
+    std::vector<std::string> sv;
+    for (size_t i = 0; i < iv.size(); i++) { iv[i] = (int32_t)((i * 2654435761u) % 1000) - 500; iw[i] = (int32_t)(i * 2654435761u); }
+    for (size_t i = 0; i < lv.size(); i++) lv[i] = 1500000000000LL + (int64_t)i * 977 + (int64_t)(i % 13);
+    for (size_t i = 0; i < fv.size(); i++) fv[i] = (float)((i * 40503u) % 10000) / 10.0f;
+    for (size_t i = 0; i < dv.size(); i++) dv[i] = (double)((i * 69069u) % 50000) / 10.0;
+    for (int i = 0; i < 25000; i++) sv.push_back("www.host" + std::to_string((i * 7) % 300) + ".com/p/" + std::to_string((i * 13) % 41));
+    struct P { uint8_t dt; bool idx; DataPack pack; };
+    std::vector<P> ps;
+    ps.push_back({ColumnType::INT, false, DataPack::fromInts(iv.data(), (int)iv.size())});
+    ps.push_back({ColumnType::INT, false, DataPack::fromInts(iw.data(), (int)iw.size())});  // too many distinct values: DELTA
+    ps.push_back({ColumnType::INT, true, DataPack::fromInts(iw.data(), (int)iw.size())});
+    ps.push_back({ColumnType::LONG, false, DataPack::fromLongs(lv.data(), (int)lv.size())});
+    ps.push_back({ColumnType::FLOAT, false, DataPack::fromFloats(fv.data(), (int)fv.size())});
+    ps.push_back({ColumnType::DOUBLE, true, DataPack::fromDoubles(dv.data(), (int)dv.size())});
+    ps.push_back({ColumnType::STRING, false, DataPack::fromStrings(sv)});
+    PackEncodeBatch eb(0);
+    for (auto& p : ps) eb.add(p.dt, p.idx, p.pack);
+    eb.run();
+    int delta = 0;
+    for (size_t i = 0; i < ps.size(); i++) {
+        DataPack host = ps[i].pack;
+        host.compress(va, VERSION, ps[i].dt, ps[i].idx);  // the host encoder
+        const DataPackNode& d = eb.dpn((int)i);
+        CHECK(same(eb.cmpData((int)i), host.cmpData()));
+        CHECK(d.encodeType == host.dpn().encodeType && d.packSize == host.dpn().packSize && d.compress && d.objCount == host.dpn().objCount && d.dataSize == host.dpn().dataSize);
+        CHECK(d.minValue == host.dpn().minValue && d.maxValue == host.dpn().maxValue && d.sum == host.dpn().sum);
+        int64_t mn = 0, mx = 0, sm = 0;
+        if (ps[i].dt != ColumnType::STRING) {
+            CHECK(ixo_pack_stats(ps[i].dt, d.objCount, ps[i].pack.data().address(), &mn, &mx, &sm) == 0);
+            CHECK(d.minValue == mn && d.maxValue == mx && d.sum == sm);
+        }
+        delta += d.encodeType == CodecType::DELTA;
+        DataPack back = eb.pack((int)i);
+        back.dropData();
+        back.decompress(va, VERSION, ps[i].dt);
+        CHECK(same(back.data(), ps[i].pack.data()));
+    }
+    CHECK(delta == 1);
+}
+
 int main(int argc, char** argv) {
     if (argc < 3) { std::fprintf(stderr, "usage: host_test --cpu|--gpu <tmpdir>\n"); return 2; }
     const std::string mode = argv[1], dir = argv[2];
@@ -292,6 +411,8 @@ int main(int argc, char** argv) {
             test_pack_literals(va, true);
             test_dict_struct_and_errors(va);
             test_segment_scan_gpu(va, dir);
+            test_ext_index_gpu(va);
+            test_encode_batch_gpu(va);
         } else {
             return 2;
         }
