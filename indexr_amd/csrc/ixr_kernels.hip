@@ -1276,6 +1276,68 @@ __global__ __launch_bounds__(64) void k_front_combine(const DevPack* __restrict_
 // strings of up to 64 bytes with one load and one store per lane.  The blocks' lengths and offsets are staged in LDS (one
 // 16-byte record per string, read back as a broadcast within each group of 16 lanes).  Columns 64.. take further rounds.
 __device__ __forceinline__ uint32_t byte_mask(uint32_t x) { return x >= 4 ? 0xFFFFFFFFu : ((1u << (8 * x)) - 1u); }
+// H rounds of 64 byte columns of one block: lane c of the block's 16 lanes owns the dwords at columns col0 + 64 h + 4 c.
+template <int H>
+__device__ __forceinline__ void front_rounds(const FrontCtx& f, const uint4* mine, uint32_t b, uint32_t col0, int c) {
+    constexpr int kB = IXR_FRONT_BATCH;  // strings per step and group
+    uint32_t j0[H], cur[H];
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+        j0[h] = col0 + 64 * h + 4 * c;
+        cur[h] = 0;
+        if (b < f.nblk) {  // the columns' bytes before the block (one uint16 each)
+            const uint2 st = *(const uint2*)(f.sum + (size_t)b * f.stride + j0[h]);
+            cur[h] = (st.x & 0xFFu) | ((st.x >> 8) & 0xFF00u) | ((st.y & 0xFFu) << 16) | ((st.y << 8) & 0xFF000000u);
+        }
+    }
+    for (uint32_t k0 = 0; k0 < (uint32_t)kFrontBlock; k0 += kB) {
+        uint4 m[kB];
+        bool reach = false;
+#pragma unroll
+        for (int q = 0; q < kB; q++) {
+            m[q] = mine[k0 + q];
+            reach |= m[q].y > j0[0];
+        }
+        if (!__any(reach)) continue;  // strings that end before these columns neither read nor write here
+        uint32_t t[H][kB];
+#pragma unroll
+        for (int h = 0; h < H; h++) {
+#pragma unroll
+            for (int q = 0; q < kB; q++) {
+                // unconditional, clamped load: where no column takes a new byte read the string's first suffix byte
+                // position (always readable: the suffix bytes are followed by the id stream and the input slack)
+                const bool fresh = j0[h] + 4 > m[q].x && j0[h] < m[q].y;
+                const int32_t at = (int32_t)(m[q].w + (fresh ? j0[h] : m[q].x));  // may lie up to 3 bytes before the suffix: pack header
+                __builtin_memcpy(&t[h][q], f.sfx + at, 4);
+            }
+        }
+        // keep the loads together: without this the compiler sinks some of them into conditional blocks behind a full
+        // wait, which costs further memory round trips per batch
+#pragma unroll
+        for (int h = 0; h < H; h++)
+#pragma unroll
+            for (int q = 0; q < kB; q += 8)
+                asm volatile("" : "+v"(t[h][q]), "+v"(t[h][q + 1]), "+v"(t[h][q + 2]), "+v"(t[h][q + 3]), "+v"(t[h][q + 4]), "+v"(t[h][q + 5]), "+v"(t[h][q + 6]), "+v"(t[h][q + 7]));
+#pragma unroll
+        for (int h = 0; h < H; h++) {
+#pragma unroll
+            for (int q = 0; q < kB; q++) {
+                const uint32_t p = m[q].x, len = m[q].y;
+                const uint32_t lo = p > j0[h] ? min(p - j0[h], 4u) : 0u, hi = len > j0[h] ? min(len - j0[h], 4u) : 0u;
+                const uint32_t take = byte_mask(hi) & ~byte_mask(lo);  // columns inside the suffix
+                cur[h] = (cur[h] & ~take) | (t[h][q] & take);
+                uint8_t* dst = f.body + m[q].z + j0[h];
+                if (hi == 4) __builtin_memcpy(dst, &cur[h], 4);
+                else if (hi) {
+                    dst[0] = (uint8_t)cur[h];
+                    if (hi > 1) dst[1] = (uint8_t)(cur[h] >> 8);
+                    if (hi > 2) dst[2] = (uint8_t)(cur[h] >> 16);
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_front_decode(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                       const PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                       uint8_t* __restrict__ out, uint8_t* __restrict__ scratch,
@@ -1288,7 +1350,6 @@ __global__ __launch_bounds__(256) void k_front_decode(const DevPack* __restrict_
     FrontCtx f;
     if (!front_ctx(f, P, metas[pi], in, out, scratch, ro, use_ds, true)) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
-    constexpr int kB = IXR_FRONT_BATCH;  // strings per step and group
     const uint32_t wave = bx * 4 + wv, nwaves = gridDim.x * 4;
     const uint32_t ntask = (f.nblk + 3) / 4;
     uint4* meta = s_meta[wv];
@@ -1309,49 +1370,11 @@ __global__ __launch_bounds__(256) void k_front_decode(const DevPack* __restrict_
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const uint32_t b = b0 + g;
         const uint4* mine = meta + g * kFrontBlock;
-        for (uint32_t col0 = 0; col0 < f.stride; col0 += 64) {
-            const uint32_t j0 = col0 + 4 * c;
-            uint32_t cur = 0;
-            if (b < f.nblk) {  // the four columns' bytes before the block (one uint16 each)
-                const uint2 st = *(const uint2*)(f.sum + (size_t)b * f.stride + j0);
-                cur = (st.x & 0xFFu) | ((st.x >> 8) & 0xFF00u) | ((st.y & 0xFFu) << 16) | ((st.y << 8) & 0xFF000000u);
-            }
-            for (uint32_t k0 = 0; k0 < (uint32_t)kFrontBlock; k0 += kB) {
-                uint4 m[kB];
-                bool reach = false;
-#pragma unroll
-                for (int q = 0; q < kB; q++) {
-                    m[q] = mine[k0 + q];
-                    reach |= m[q].y > j0;
-                }
-                if (!__any(reach)) continue;  // strings that end before these columns neither read nor write here
-                uint32_t t[kB];
-#pragma unroll
-                for (int q = 0; q < kB; q++) {
-                    // unconditional, clamped load: where no column takes a new byte read the string's first suffix byte
-                    // position (always readable: the suffix bytes are followed by the id stream and the input slack)
-                    const bool fresh = j0 + 4 > m[q].x && j0 < m[q].y;
-                    const int32_t at = (int32_t)(m[q].w + (fresh ? j0 : m[q].x));  // may lie up to 3 bytes before the suffix: pack header
-                    __builtin_memcpy(&t[q], f.sfx + at, 4);
-                }
-#pragma unroll
-                for (int q = 0; q < kB; q += 8)
-                    asm volatile("" : "+v"(t[q]), "+v"(t[q + 1]), "+v"(t[q + 2]), "+v"(t[q + 3]), "+v"(t[q + 4]), "+v"(t[q + 5]), "+v"(t[q + 6]), "+v"(t[q + 7]));
-#pragma unroll
-                for (int q = 0; q < kB; q++) {
-                    const uint32_t p = m[q].x, len = m[q].y;
-                    const uint32_t lo = p > j0 ? min(p - j0, 4u) : 0u, hi = len > j0 ? min(len - j0, 4u) : 0u;
-                    const uint32_t take = byte_mask(hi) & ~byte_mask(lo);  // columns inside the suffix
-                    cur = (cur & ~take) | (t[q] & take);
-                    uint8_t* dst = f.body + m[q].z + j0;
-                    if (hi == 4) __builtin_memcpy(dst, &cur, 4);
-                    else if (hi) {
-                        dst[0] = (uint8_t)cur;
-                        if (hi > 1) dst[1] = (uint8_t)(cur >> 8);
-                        if (hi > 2) dst[2] = (uint8_t)(cur >> 16);
-                    }
-                }
-            }
+        // two rounds of 64 columns at a time where there are that many (a lane owns dword c of both): their loads are in
+        // flight together and the strings' records are read once for both
+        for (uint32_t col0 = 0; col0 < f.stride; col0 += 128) {
+            if (col0 + 64 < f.stride) front_rounds<2>(f, mine, b, col0, c);  // wave-uniform
+            else front_rounds<1>(f, mine, b, col0, c);
         }
     }
 }
