@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $ROOT/bench.py --cpu-seconds 0 $*"
+B="python3 $ROOT/bench.py --cpu-seconds 0 --no-exclusive $*"
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/bench_stats.json 2> $O/stats.log
 echo "stats pass done"
 timeout -s KILL 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B --steps 2 --warmup 1 --no-verify > /dev/null 2> $O/pmc_fetch.log
