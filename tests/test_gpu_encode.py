@@ -272,3 +272,32 @@ def test_gpu_encoder_on_random_packs():
     finally:
         d_data.free()
         d_out.free()
+
+
+@pytest.mark.gpu
+def test_gpu_encoder_rejects_descriptors_that_leave_the_arenas():
+    """what the kernels would index with is checked on the host: nothing is launched for a bad batch"""
+    data = O.rows_to_bytes(np.arange(1000, dtype="<i4"), O.INT)
+    cap = L.lib.ixr_compress_bound(1000, 4000)
+    d_data, d_out = L.DeviceBuffer(0, 4096), L.DeviceBuffer(0, cap + 64)
+    try:
+        d_data.upload(np.concatenate([data, np.zeros(96, dtype=np.uint8)]))
+        good = (0, 0, O.INT, 0, 1000, 4000, 0, 0, 0, 0, 0)
+        arr, bad = L.encode_run([L.EncodeDesc(*good)], d_data.ptr, 4096, d_out.ptr, cap + 64)
+        assert bad == 0 and arr[0].pack_size > 0
+        for change in ({0: 4096 - 3984}, {0: 8}, {1: 8}, {1: 64 + 16}, {2: 7}, {4: 999}, {4: 0}, {4: 70000}, {5: 3996}):
+            f = list(good)
+            for k, v in change.items():
+                f[k] = v
+            with pytest.raises(L.IxrError) as e:
+                L.encode_run([L.EncodeDesc(*f)], d_data.ptr, 4096, d_out.ptr, cap + 64)
+            assert e.value.code in (L.ERR_INVALID_ARGUMENT, -102), change
+        # string pack whose offsets leave the body: found on the device, reported per pack
+        s = O.rows_to_bytes([b"ab", b"c", b"def"], O.STRING).copy()
+        s[8:12] = np.frombuffer(np.int32(77).tobytes(), dtype=np.uint8)
+        d_data.upload(np.concatenate([s, np.zeros(4096 - len(s), dtype=np.uint8)]))
+        arr, bad = L.encode_run([L.EncodeDesc(0, 0, O.STRING, 0, 3, len(s), 0, 0, 0, 0, 0)], d_data.ptr, 4096, d_out.ptr, cap + 64)
+        assert bad == 1 and arr[0].pack_size == L.ERR_INVALID_ARGUMENT
+    finally:
+        d_data.free()
+        d_out.free()

@@ -124,3 +124,19 @@ def test_decode_without_gpu_fails_loudly():
     assert r in (L.ERR_NO_DEVICE, L.ERR_HIP)
     with pytest.raises(L.IxrError):
         L.Plan(0, [L.PackDesc(0, 0, len(pack), 40, 10, et, L.INT, 0)])
+
+
+def test_neighbouring_entry_points_fail_loudly_without_gpu():
+    # encode, row filters and hand-back have no CPU path either
+    if L.lib.ixr_device_count() > 0:
+        pytest.skip("a GPU is present")
+    fake = 0x10000  # never dereferenced: the device check comes first
+    with pytest.raises(L.IxrError) as e:
+        L.encode_run([L.EncodeDesc(0, 0, L.INT, 0, 10, 40, 0, 0, 0, 0, 0)], fake, 64, fake, 4096)
+    assert e.value.code in (L.ERR_NO_DEVICE, L.ERR_HIP)
+    with pytest.raises(L.IxrError) as e:
+        L.scan_filter_run([L.ScanFilterDesc(0, 0, L.INT, 10, 40, L.FILTER_EQUAL, 1, 0)], fake, 64, np.zeros(16, dtype=np.uint8), fake, 8192)
+    assert e.value.code in (L.ERR_NO_DEVICE, L.ERR_HIP)
+    with pytest.raises(L.IxrError) as e:
+        L.handback_run([L.HandbackDesc(0, 0, 10, 40, L.SQL_INT, 0, 10, 0)], fake, 64, fake, 64)
+    assert e.value.code in (L.ERR_NO_DEVICE, L.ERR_HIP)

@@ -221,3 +221,30 @@ def test_gpu_scan_filter_on_the_output_of_a_decode():
     finally:
         plan.destroy()
         d_in.free(); d_out.free(); d_bm.free()
+
+
+@pytest.mark.gpu
+def test_gpu_scan_filter_rejects_bad_descriptors():
+    data = O.rows_to_bytes(np.arange(100, dtype="<i4"), O.INT)
+    d_dec, d_bm = L.DeviceBuffer(0, 1024), L.DeviceBuffer(0, L.BITMAP_BYTES)
+    try:
+        d_dec.upload(np.concatenate([data, np.zeros(1024 - 400, dtype=np.uint8)]))
+        values = np.zeros(24, dtype=np.uint8)
+        good = (0, 0, O.INT, 100, 400, L.FILTER_EQUAL, 1, 0)
+        res, bad = L.scan_filter_run([L.ScanFilterDesc(*good)], d_dec.ptr, 1024, values, d_bm.ptr, L.BITMAP_BYTES)
+        assert bad == 0 and res[0] == L.BITMAP_SOME
+        for change in ({0: 1024}, {0: 4}, {1: 24}, {1: 4}, {2: 9}, {3: 0}, {3: 70000}, {5: 0}, {5: 7}, {6: 0}, {6: 4}):
+            f = list(good)
+            for k, v in change.items():
+                f[k] = v
+            with pytest.raises(L.IxrError) as e:
+                L.scan_filter_run([L.ScanFilterDesc(*f)], d_dec.ptr, 1024, values, d_bm.ptr, L.BITMAP_BYTES)
+            assert e.value.code == L.ERR_INVALID_ARGUMENT, change
+        with pytest.raises(L.IxrError):
+            L.scan_filter_run([L.ScanFilterDesc(*good)], d_dec.ptr, 1024, values, d_bm.ptr, L.BITMAP_BYTES - 8)
+        # a data_size too small for the rows is reported per pack
+        res, bad = L.scan_filter_run([L.ScanFilterDesc(0, 0, O.INT, 100, 396, L.FILTER_EQUAL, 1, 0)], d_dec.ptr, 1024, values, d_bm.ptr, L.BITMAP_BYTES)
+        assert bad == 1 and res[0] == L.ERR_INVALID_ARGUMENT
+    finally:
+        d_dec.free()
+        d_bm.free()
