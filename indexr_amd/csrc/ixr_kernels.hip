@@ -1277,8 +1277,19 @@ __global__ __launch_bounds__(64) void k_front_combine(const DevPack* __restrict_
 // 16-byte record per string, read back as a broadcast within each group of 16 lanes).  Columns 64.. take further rounds.
 __device__ __forceinline__ uint32_t byte_mask(uint32_t x) { return x >= 4 ? 0xFFFFFFFFu : ((1u << (8 * x)) - 1u); }
 // H rounds of 64 byte columns of one block: lane c of the block's 16 lanes owns the dwords at columns col0 + 64 h + 4 c.
+#ifdef IXR_FRONT_EXACT_TAILS  // build switch: every tail byte by byte
+constexpr bool kFrontWholeTails = false;
+#else
+constexpr bool kFrontWholeTails = true;
+#endif
+// A string's last dword is stored whole where that is safe: the bytes past its end belong to the strings after it, which
+// this wave writes later (stores of one wave to the same bytes land in program order) -- as long as they stay inside the
+// block (`block_end` = body offset where the block's last string ends; the next block is another wave's) and no string
+// has been written ahead of its predecessors' tails (only the first 128 columns, string by string: `whole_tails`).
+// Everywhere else the tail goes out byte by byte.
 template <int H>
-__device__ __forceinline__ void front_rounds(const FrontCtx& f, const uint4* mine, uint32_t b, uint32_t col0, int c) {
+__device__ __forceinline__ void front_rounds(const FrontCtx& f, const uint4* mine, uint32_t b, uint32_t col0, int c, uint32_t block_end,
+                                             bool whole_tails) {
     constexpr int kB = IXR_FRONT_BATCH;  // strings per step and group
     uint32_t j0[H], cur[H];
 #pragma unroll
@@ -1319,15 +1330,16 @@ __device__ __forceinline__ void front_rounds(const FrontCtx& f, const uint4* min
             for (int q = 0; q < kB; q += 8)
                 asm volatile("" : "+v"(t[h][q]), "+v"(t[h][q + 1]), "+v"(t[h][q + 2]), "+v"(t[h][q + 3]), "+v"(t[h][q + 4]), "+v"(t[h][q + 5]), "+v"(t[h][q + 6]), "+v"(t[h][q + 7]));
 #pragma unroll
-        for (int h = 0; h < H; h++) {
+        for (int q = 0; q < kB; q++) {  // string by string, so that a string's tail is stored before anything of the next one
 #pragma unroll
-            for (int q = 0; q < kB; q++) {
+            for (int h = 0; h < H; h++) {
                 const uint32_t p = m[q].x, len = m[q].y;
                 const uint32_t lo = p > j0[h] ? min(p - j0[h], 4u) : 0u, hi = len > j0[h] ? min(len - j0[h], 4u) : 0u;
                 const uint32_t take = byte_mask(hi) & ~byte_mask(lo);  // columns inside the suffix
                 cur[h] = (cur[h] & ~take) | (t[h][q] & take);
-                uint8_t* dst = f.body + m[q].z + j0[h];
-                if (hi == 4) __builtin_memcpy(dst, &cur[h], 4);
+                const uint32_t at = m[q].z + j0[h];
+                uint8_t* dst = f.body + at;
+                if (hi == 4 || (hi && kFrontWholeTails && whole_tails && at + 4 <= block_end)) __builtin_memcpy(dst, &cur[h], 4);
                 else if (hi) {
                     dst[0] = (uint8_t)cur[h];
                     if (hi > 1) dst[1] = (uint8_t)(cur[h] >> 8);
@@ -1343,6 +1355,7 @@ __global__ __launch_bounds__(256) void k_front_decode(const DevPack* __restrict_
                                                       uint8_t* __restrict__ out, uint8_t* __restrict__ scratch,
                                                       const uint8_t* __restrict__ ro, int use_ds) {
     __shared__ uint4 s_meta[4][4 * kFrontBlock];  // per wave: (prefixLen, length, body offset, suffix position - prefixLen)
+    __shared__ uint32_t s_end[4][4];              // per wave and block: body offset where the block's last string ends
     uint32_t bx, by;
     pack_block_remap(bx, by);
     const int pi = list[by];
@@ -1363,18 +1376,25 @@ __global__ __launch_bounds__(256) void k_front_decode(const DevPack* __restrict_
             const uint32_t ii = min(i, f.ec - 1);
             const uint32_t p = (uint32_t)f.pre[ii];
             const uint32_t len = i < f.ec ? p + (uint32_t)f.suf[ii] : 0u;  // length 0: no column takes part
-            meta[q * kFrontBlock + lane] = make_uint4(p, len, f.doff[ii], f.sufoff[ii] - p);
+            const uint32_t o = f.doff[ii];
+            meta[q * kFrontBlock + lane] = make_uint4(p, len, o, f.sufoff[ii] - p);
+            // strings past the list's end have length 0 and the last string's offset: the maximum is the block's end
+            uint32_t e = o + len;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) e = max(e, (uint32_t)__shfl_xor(e, d));
+            if (lane == 0) s_end[wv][q] = e;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const uint32_t b = b0 + g;
         const uint4* mine = meta + g * kFrontBlock;
+        const uint32_t block_end = s_end[wv][g];
         // two rounds of 64 columns at a time where there are that many (a lane owns dword c of both): their loads are in
         // flight together and the strings' records are read once for both
         for (uint32_t col0 = 0; col0 < f.stride; col0 += 128) {
-            if (col0 + 64 < f.stride) front_rounds<2>(f, mine, b, col0, c);  // wave-uniform
-            else front_rounds<1>(f, mine, b, col0, c);
+            if (col0 + 64 < f.stride) front_rounds<2>(f, mine, b, col0, c, block_end, col0 == 0 && f.stride <= 128);  // wave-uniform
+            else front_rounds<1>(f, mine, b, col0, c, block_end, col0 == 0);
         }
     }
 }
