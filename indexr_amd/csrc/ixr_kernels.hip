@@ -691,9 +691,12 @@ __global__ __launch_bounds__(256) void k_delta(const DevPack* __restrict__ packs
     constexpr int V = sizeof(U) == 4 ? 8 : 4;
     constexpr uint32_t kChunk = 256 * V;  // values per workgroup iteration
     __shared__ U wsum[2][4];
+    __shared__ uint32_t s_win[12][256];  // per thread: the up to 48 bytes its V values are packed in, dword k at [k][tid]
     U carry = (U)s.first;
     int buf = 0;
-    // unpack the V values of this thread for the chunk starting at c0 (minDelta already added); zeros past the end
+    // unpack the V values of this thread for the chunk starting at c0 (minDelta already added); zeros past the end.
+    // The V values sit in V * bw consecutive bits: they are fetched with one to three 16-byte loads (instead of two or three
+    // dword loads per value), parked in the thread's LDS column and picked out of it at their bit offsets.
     auto unpack = [&](uint32_t c0, U (&d)[V]) {
         const uint32_t i0 = c0 + V * tid;
 #pragma unroll
@@ -701,12 +704,44 @@ __global__ __launch_bounds__(256) void k_delta(const DevPack* __restrict__ packs
         if (i0 < n) {
             const uint32_t hdr = mb[i0 >> 5];
             const uint32_t bw = hdr >> 24;
-            const uint8_t* src = base + (hdr & 0xFFFFFFu);
             const U md = (U)min_delta[i0 >> 7];
-            const uint32_t bit = (i0 & 31) * bw;
+            if (bw == 0) {
 #pragma unroll
-            for (int q = 0; q < V; q++)
-                if (i0 + q < n) d[q] = extract<U>(src, bit + q * bw, bw) + md;
+                for (int q = 0; q < V; q++)
+                    if (i0 + q < n) d[q] = md;
+                return;
+            }
+            const uint32_t bit = (i0 & 31) * bw;
+            const uintptr_t a = (uintptr_t)(base + (hdr & 0xFFFFFFu) + (bit >> 3));
+            const uint8_t* al = (const uint8_t*)(a & ~(uintptr_t)3);
+            const uint32_t sh = ((uint32_t)(a & 3) << 3) + (bit & 7);  // 0..31
+            // bits of this thread's values that exist: a load reaches less than 16 bytes past them (the arena's slack)
+            const uint32_t nbits = sh + min((uint32_t)V, n - i0) * bw;  // <= 31 + 256
+            uint4 w[3];
+            __builtin_memcpy(&w[0], al, 16);
+            w[1] = w[2] = make_uint4(0, 0, 0, 0);
+            if (nbits > 128) __builtin_memcpy(&w[1], al + 16, 16);
+            if (nbits > 256) __builtin_memcpy(&w[2], al + 32, 16);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                s_win[4 * k + 0][tid] = w[k].x; s_win[4 * k + 1][tid] = w[k].y;
+                s_win[4 * k + 2][tid] = w[k].z; s_win[4 * k + 3][tid] = w[k].w;
+            }
+#pragma unroll
+            for (int q = 0; q < V; q++) {
+                if (i0 + q < n) {
+                    const uint32_t off = sh + q * bw, k = off >> 5, r = off & 31;
+                    const uint64_t lo = (uint64_t)s_win[k][tid] | ((uint64_t)s_win[k + 1][tid] << 32);
+                    if constexpr (sizeof(U) == 4) {
+                        const uint32_t v = (uint32_t)(lo >> r);
+                        d[q] = (bw >= 32 ? v : (v & ((1u << bw) - 1u))) + md;
+                    } else {
+                        const uint64_t hi = s_win[k + 2][tid];
+                        const uint64_t v = r ? ((lo >> r) | (hi << (64 - r))) : lo;
+                        d[q] = (bw >= 64 ? v : (v & ((1ull << bw) - 1ull))) + md;
+                    }
+                }
+            }
         }
     };
     U d[V];
