@@ -1473,21 +1473,16 @@ __global__ __launch_bounds__(256) void k_row_scan(const DevPack* __restrict__ pa
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_str_index: string dictionary packs, one workgroup of 4 waves per pack (a small workgroup finds room on a compute unit
-// while the numeric kernels of the other stream keep the device busy; 16 waves waited).  Per round each wave expands one tile of
+// k_str_index: string dictionary packs, one workgroup of 4 or 16 waves per pack (see the launcher).  Per round each wave expands one tile of
 // kRleTile ids, looks up the rows' dictionary slices and scans the row lengths; the workgroup chains the tiles and the
 // rounds with a running total.  Writes the output index (offset[0] = 0, offset[i+1] = offset[i] + len[i];
 // StringsStruct.Builder, StringsStruct.java:120-158) and each row's slice start into scratch, checks that the body fits,
 // zero-fills what the body leaves of dpn.dataSize.  (DictStruct.decodeStrings, DictStruct.java:97-110.)
 // ---------------------------------------------------------------------------------------------------------------
-#ifndef IXR_STR_INDEX_WAVES
-#define IXR_STR_INDEX_WAVES 4
-#endif
-constexpr int kStrIndexWaves = IXR_STR_INDEX_WAVES;
-__global__ __launch_bounds__(kStrIndexWaves * 64) void k_str_index(const DevPack* __restrict__ packs, const int* __restrict__ list,
+template <int kWaves>
+__global__ __launch_bounds__(kWaves * 64) void k_str_index(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                     PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ scratch) {
-    constexpr int kWaves = kStrIndexWaves;
     __shared__ uint16_t s_ids[kWaves][kRleTile];
     __shared__ __align__(16) uint8_t s_win[kWaves][kWinAlloc];
     __shared__ uint32_t s_wsum[2][kWaves];
@@ -2317,7 +2312,10 @@ void launch_front_decode(const LaunchCtx& c, const int* list, int count, int use
 }
 void launch_str_index(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_str_index, dim3(count), dim3(kStrIndexWaves * 64), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+    // few packs: 16 waves each shorten the one pack's chain of rounds; many packs: workgroups of 4 waves, which find room on
+    // a compute unit beside the numeric kernels of the other stream
+    if (count < 1024) hipLaunchKernelGGL(k_str_index<16>, dim3(count), dim3(1024), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+    else hipLaunchKernelGGL(k_str_index<4>, dim3(count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
 }
 void launch_row_scan(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;
