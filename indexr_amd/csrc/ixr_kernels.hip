@@ -1515,23 +1515,38 @@ __global__ __launch_bounds__(kWaves * 64) void k_str_index(const DevPack* __rest
         const uint32_t tile_start = min(tile * (uint32_t)kRleTile, n), tile_end = min(n, tile_start + (uint32_t)kRleTile);
         const uint32_t cnt = tile_end - tile_start;  // 0 for waves past the last tile
         if (cnt) rle_tile_expand(w, id_bw, ids_end, restarts[tile], tile_start, tile_end, ids);
+        // a lane takes four neighbouring rows of every 256: ids come out of LDS four at a time, the index and the source
+        // offsets leave as 16-byte stores
         uint2 ab[16];
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const uint32_t r = q * 64 + lane;
-            uint32_t id = r < cnt ? ids[r] : 0u;
-            if (id >= ec) { bad = true; id = 0; }
-            __builtin_memcpy(&ab[q], doff + id, 8);  // doff[id], doff[id + 1]
+        for (int q = 0; q < 4; q++) {
+            const uint32_t r = q * 256 + 4 * lane;
+            const uint2 four = ((const uint2*)ids)[q * 64 + lane];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                uint32_t id = ((g < 2 ? four.x : four.y) >> (16 * (g & 1))) & 0xFFFFu;
+                if (r + g >= cnt) id = 0;
+                if (id >= ec) { bad = true; id = 0; }
+                __builtin_memcpy(&ab[q * 4 + g], doff + id, 8);  // doff[id], doff[id + 1]
+            }
         }
-        // rows are dealt to lanes 64 at a time: scan each group of 64 across the wave, chain the groups
+        // scan each group of 256 rows across the wave (four rows per lane), chain the groups
         uint32_t ex[16], run = 0;
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const uint32_t r = q * 64 + lane;
-            const uint32_t len = r < cnt ? ab[q].y - ab[q].x : 0u;
-            sum64 += len;
-            const uint32_t inc = wave_incl_scan(len);
-            ex[q] = run + inc - len;
+        for (int q = 0; q < 4; q++) {
+            const uint32_t r = q * 256 + 4 * lane;
+            uint32_t len[4], s4 = 0;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                len[g] = r + g < cnt ? ab[q * 4 + g].y - ab[q * 4 + g].x : 0u;
+                ex[q * 4 + g] = s4;
+                s4 += len[g];
+            }
+            sum64 += s4;
+            const uint32_t inc = wave_incl_scan(s4);
+            const uint32_t first = run + inc - s4;
+#pragma unroll
+            for (int g = 0; g < 4; g++) ex[q * 4 + g] += first;
             run += __builtin_amdgcn_readlane(inc, 63);
         }
         if (lane == 0) s_wsum[round & 1][wave] = run;
@@ -1545,9 +1560,16 @@ __global__ __launch_bounds__(kWaves * 64) void k_str_index(const DevPack* __rest
         }
         const uint32_t o0 = carry + before;
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const uint32_t r = q * 64 + lane;
-            if (r < cnt) { off[tile_start + r] = o0 + ex[q]; srcoff[tile_start + r] = ab[q].x; }
+        for (int q = 0; q < 4; q++) {
+            const uint32_t r = q * 256 + 4 * lane;
+            if (r + 3 < cnt) {
+                *(uint4*)(off + tile_start + r) = make_uint4(o0 + ex[q * 4], o0 + ex[q * 4 + 1], o0 + ex[q * 4 + 2], o0 + ex[q * 4 + 3]);
+                *(uint4*)(srcoff + tile_start + r) = make_uint4(ab[q * 4].x, ab[q * 4 + 1].x, ab[q * 4 + 2].x, ab[q * 4 + 3].x);
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    if (r + g < cnt) { off[tile_start + r + g] = o0 + ex[q * 4 + g]; srcoff[tile_start + r + g] = ab[q * 4 + g].x; }
+            }
         }
         carry += total;
     }
