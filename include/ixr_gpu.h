@@ -168,7 +168,8 @@ int32_t ixr_get_data_from_dict_struct(int32_t device, int32_t data_type, int32_t
  *                r >> 6 (BitMap / DirectBitMap, indexr-common/.../util/DirectBitMap.java); all 1024 words are written
  *   results[i]   IXR_BITMAP_NONE / IXR_BITMAP_ALL (the reference returns its constants; the bitmap is all zeros / ones up to
  *                objCount) / IXR_BITMAP_SOME, or a negative error: IXR_ERR_DATA_IMPROPER for a pack that is not
- *                DICT_COMPRESS (the reference gives those another index class), IXR_ERR_BUG where the reference's
+ *                DICT_COMPRESS (the reference gives those ExtIndex_SimpleBits: decode them with ixr_plan_run and use
+ *                ixr_scan_filter_run), IXR_ERR_BUG where the reference's
  *                Preconditions.checkState fails (between :165-166), decode errors as in ixr_plan_status
  * The call synchronises with `stream`.  Returns the number of packs with a negative result, or a negative library error.
  */
