@@ -57,6 +57,7 @@ struct EncPack {
     uint64_t s_rep;       // scratch: uint32 per row: the row that represents its string in the table
     uint64_t s_rank;      // scratch: uint16 per row: dictionary id of the string a representative row holds
     uint64_t s_perm;      // scratch: uint32 representative rows, sorted by their strings: slot e holds entry e (n2 slots)
+    uint64_t s_key;       // scratch: uint64 per sort slot: the first 8 bytes of the slot's string, big endian (n2 slots)
     uint64_t s_pre;       // scratch: uint32 prefixLen per entry (front coding)
     uint64_t s_suf;       // scratch: uint32 suffixLen per entry
     uint64_t s_ent_off;   // scratch: uint32 offset of entry e in the dictionary body, obj_count + 1 entries
@@ -633,7 +634,8 @@ __global__ __launch_bounds__(kEncThreads) void k_enc_pack(const EncPack* __restr
 //   then length), DictStructUtil.compress :25-81 (entries plain as a StringsStruct, or front coded by
 //   DeltaCodec.encodeStrings :268-352 when there are >= 64 entries in >= 256 bytes), ids as RLE / bit-packing hybrid.
 // Steps: the offsets are checked; a hash table finds one representative row per distinct string; a bitonic sort orders the
-// representatives by their strings (compare-exchange pairs spread over the workgroup, one barrier per stage): slot e is
+// representatives by their strings (8-byte prefix keys first, the strings on ties; compare-exchange pairs spread over the
+// workgroup, one barrier per stage): slot e is
 // dictionary entry e, and a row's id is the slot of its representative; entry lengths, common prefixes with the entry
 // before and their running sums give every byte its place; the writers are those of the numeric packs.
 // ---------------------------------------------------------------------------------------------------------------
@@ -740,29 +742,46 @@ __global__ __launch_bounds__(kEncThreads) void k_enc_str(const EncPack* __restri
     }
     __syncthreads();
     TICK(1);
-    // the representatives, compacted in row order, are what gets sorted
+    // the representatives, compacted in row order, are what gets sorted.  Each carries the first 8 bytes of its string as a
+    // big-endian number (zero padded): where two such keys differ they decide the order, and the strings themselves are
+    // read only on ties (equal strings never meet: every string is here once).  Keys of 16 bytes were not faster.
     uint32_t* perm = (uint32_t*)(scratch + P.s_perm);
+    uint64_t* keys = (uint64_t*)(scratch + P.s_key);
     uint32_t carry = 0;
     for (int base = 0; base < n; base += kEncThreads) {
         const int i = base + tid;
         const bool mine = i < n && rep[i] == (uint32_t)i;
         uint32_t tot;
         const uint32_t ex = wg_excl_scan(mine ? 1u : 0u, s_w, &tot);
-        if (mine) perm[carry + ex] = (uint32_t)i;
+        if (mine) {
+            const int32_t a0 = off[i], len = off[i + 1] - a0;
+            const uint8_t* sp = S.body + a0;
+            uint64_t key = 0;
+            for (int q = 0; q < 8; q++) key = (key << 8) | (q < len ? (uint64_t)sp[q] : 0ull);
+            perm[carry + ex] = (uint32_t)i;
+            keys[carry + ex] = key;
+        }
         carry += tot;
     }
     const int ec = (int)carry;
     uint32_t m2 = 2;
     while (m2 < (uint32_t)ec) m2 <<= 1;
-    for (uint32_t i = ec + tid; i < m2; i += kEncThreads) perm[i] = kSortPad;
+    for (uint32_t i = ec + tid; i < m2; i += kEncThreads) { perm[i] = kSortPad; keys[i] = ~0ull; }
     __syncthreads();
     for (uint32_t k = 2; k <= m2; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             for (uint32_t t = tid; t < m2 / 2; t += kEncThreads) {
                 const uint32_t i = 2 * j * (t / j) + (t % j), l = i + j;
-                const uint32_t a = perm[i], b = perm[l];
+                const uint64_t ka = keys[i], kb = keys[l];
                 const bool up = (i & k) == 0;
-                if (S.after(a, b) == up && a != b) { perm[i] = b; perm[l] = a; }
+                bool after;  // does slot i's string sort after slot l's?
+                uint32_t a = 0, b = 0;
+                if (ka != kb) after = ka > kb;
+                else { a = perm[i]; b = perm[l]; after = S.after(a, b); }
+                if (after == up) {
+                    if (ka != kb) { a = perm[i]; b = perm[l]; }
+                    if (a != b) { perm[i] = b; perm[l] = a; keys[i] = kb; keys[l] = ka; }
+                }
             }
             __syncthreads();
         }
@@ -885,7 +904,7 @@ uint64_t layout_pack(EncPack& p, uint64_t off) {
     p.s_heads = take((nn + 1) * 4);
     p.s_segs = take((nn + 1) * 4);
     p.s_pos = take((nn + 1) * 4);
-    p.s_entries = p.s_table = p.s_rep = p.s_rank = p.s_perm = p.s_pre = p.s_suf = p.s_ent_off = p.s_suf_off = 0;
+    p.s_entries = p.s_table = p.s_rep = p.s_rank = p.s_perm = p.s_key = p.s_pre = p.s_suf = p.s_ent_off = p.s_suf_off = 0;
     if (p.data_type == IXR_STRING) {
         uint64_t n2 = 2;
         while (n2 < nn) n2 <<= 1;
@@ -893,6 +912,7 @@ uint64_t layout_pack(EncPack& p, uint64_t off) {
         p.s_rep = take(nn * 4);
         p.s_rank = take(nn * 2);
         p.s_perm = take(n2 * 4);
+        p.s_key = take(n2 * 8);
         p.s_pre = take(nn * 4);
         p.s_suf = take(nn * 4);
         p.s_ent_off = take((nn + 1) * 4);
