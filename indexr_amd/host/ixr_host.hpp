@@ -297,6 +297,53 @@ public:
         const int32_t a = data_.getInt(4 * (size_t)i), b = data_.getInt(4 * (size_t)(i + 1));
         return std::string_view((const char*)data_.address() + 4 * ((size_t)dpn_.objCount + 1) + a, (size_t)(b - a));
     }
+    // DataPack.uniformValAt (:196-214), version >= 1: ints and longs as they are, float / double as the raw bits of the
+    // value widened to double
+    int64_t uniformValAt(int i, uint8_t dataType) const {
+        switch (dataType) {
+            case ColumnType::INT: return intValueAt(i);
+            case ColumnType::LONG: return longValueAt(i);
+            case ColumnType::FLOAT: return floatToLong(floatValueAt(i));
+            case ColumnType::DOUBLE: return doubleToLong(doubleValueAt(i));
+            default: throw std::runtime_error("unsupported type " + std::to_string(dataType));
+        }
+    }
+    // DataPack.rawValueAt(index, BytePiece) (:531-558): address and length of a string row, no copy
+    struct BytePiece { const uint8_t* addr = nullptr; int len = 0; };
+    void rawValueAt(int i, BytePiece& bytes) const {
+        const std::string_view v = stringValueAt(i);
+        bytes.addr = (const uint8_t*)v.data();
+        bytes.len = (int)v.size();
+    }
+    // DataPack.foreach(start, count, XxxSetter) (:257-272, 308-323, 359-374, 410-425, 628-666): setter(index, value)
+    template <typename F> void foreachInt(int start, int count, F setter) const { range(start, count); for (int i = start; i < start + count; i++) setter(i, intValueAt(i)); }
+    template <typename F> void foreachLong(int start, int count, F setter) const { range(start, count); for (int i = start; i < start + count; i++) setter(i, longValueAt(i)); }
+    template <typename F> void foreachFloat(int start, int count, F setter) const { range(start, count); for (int i = start; i < start + count; i++) setter(i, floatValueAt(i)); }
+    template <typename F> void foreachDouble(int start, int count, F setter) const { range(start, count); for (int i = start; i < start + count; i++) setter(i, doubleValueAt(i)); }
+    template <typename F> void foreachBytes(int start, int count, F setter) const {
+        range(start, count);
+        BytePiece bp;
+        for (int i = start; i < start + count; i++) { rawValueAt(i, bp); setter(i, bp); }
+    }
+    // DataPack.foreach(BitMap position, XxxSetter) (:273-306 and siblings): the set rows below objCount, in order; returns
+    // how many.  `words` is a row bitmap as the filters produce it (row r = bit r & 63 of word r >> 6); nullptr stands for
+    // BitMap.ALL.  `at(i)` is one of the xxxValueAt accessors.
+    template <typename At, typename F> int foreachAt(const uint64_t* words, At at, F setter) const {
+        const int n = dpn_.objCount;
+        if (!words) { for (int i = 0; i < n; i++) setter(i, at(i)); return n; }
+        int count = 0;
+        for (int w = 0; w * 64 < n; w++) {
+            uint64_t bits = words[w];
+            while (bits) {
+                const int i = w * 64 + __builtin_ctzll(bits);
+                bits &= bits - 1;
+                if (i >= n) return count;
+                setter(i, at(i));
+                count++;
+            }
+        }
+        return count;
+    }
 
 private:
     static void check_count(int n) {
@@ -305,6 +352,9 @@ private:
     int idx(int i) const {
         if (i < 0 || i >= dpn_.objCount) throw std::out_of_range("row index");
         return i;
+    }
+    void range(int start, int count) const {
+        if (start < 0 || count < 0 || start + count > dpn_.objCount) throw std::out_of_range("row range");
     }
     template <typename T, typename F> static DataPack numbers(const T* v, int n, F uniform, bool is_fp) {
         check_count(n);

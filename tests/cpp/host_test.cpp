@@ -118,6 +118,40 @@ static void test_creators_and_compress(VersionAdapter& va) {
     CHECK_THROWS(DataPack::fromInts(iv, 0), "row count");
     CHECK_THROWS(p.intValueAt(11), "row index");
 }
+// DataPack.foreach / uniformValAt / rawValueAt on decoded (never compressed) packs: plain host code
+static void test_accessors() {
+    const int32_t iv[] = {5, -3, 7, 7, 0, 2147483647};
+    DataPack p = DataPack::fromInts(iv, 6);
+    int64_t sum = 0; int seen = 0;
+    p.foreachInt(1, 4, [&](int i, int32_t v) { CHECK(v == iv[i]); sum += v; seen++; });
+    CHECK(seen == 4 && sum == -3 + 7 + 7 + 0);
+    CHECK(p.uniformValAt(1, ColumnType::INT) == -3);
+    CHECK_THROWS(p.foreachInt(3, 4, [](int, int32_t) {}), "row range");
+    const float fv[] = {1.5f, -0.0f, 3.25f};
+    DataPack pf = DataPack::fromFloats(fv, 3);
+    CHECK(pf.uniformValAt(0, ColumnType::FLOAT) == doubleToLong(1.5) && pf.uniformValAt(1, ColumnType::FLOAT) == doubleToLong(-0.0));
+    CHECK_THROWS(pf.uniformValAt(0, ColumnType::STRING), "unsupported type");
+    const double dv[] = {2.5, 1e300};
+    DataPack pd = DataPack::fromDoubles(dv, 2);
+    double ds = 0;
+    pd.foreachDouble(0, 2, [&](int, double v) { ds += v; });
+    CHECK(ds == 2.5 + 1e300 && pd.uniformValAt(1, ColumnType::DOUBLE) == doubleToLong(1e300));
+    const std::vector<std::string> sv = {"windows", "", "mac", "linux"};
+    DataPack ps = DataPack::fromStrings(sv);
+    DataPack::BytePiece bp;
+    ps.rawValueAt(2, bp);
+    CHECK(bp.len == 3 && std::memcmp(bp.addr, "mac", 3) == 0);
+    size_t bytes = 0;
+    ps.foreachBytes(0, 4, [&](int i, const DataPack::BytePiece& b) { CHECK((size_t)b.len == sv[(size_t)i].size()); bytes += (size_t)b.len; });
+    CHECK(bytes == 7 + 0 + 3 + 5);
+    // rows picked by a bitmap: bits past objCount are ignored, nullptr is BitMap.ALL
+    const uint64_t words[1] = {0b101001ull | (1ull << 40)};
+    std::vector<int> rows;
+    const int cnt = p.foreachAt(words, [&](int i) { return p.intValueAt(i); }, [&](int i, int32_t v) { CHECK(v == iv[i]); rows.push_back(i); });
+    CHECK(cnt == 3 && rows == std::vector<int>({0, 3, 5}));
+    CHECK(p.foreachAt(nullptr, [&](int i) { return p.intValueAt(i); }, [](int, int32_t) {}) == 6);
+}
+
 static void test_segment_file_cpu(VersionAdapter& va, const std::string& dir) {
     Config1 c = build_config1(va);
     const std::string path = dir + "/config1.ixrseg";
@@ -403,6 +437,7 @@ int main(int argc, char** argv) {
             test_geometry();
             test_dpn_record();
             test_creators_and_compress(va);
+            test_accessors();
             test_segment_file_cpu(va, dir);
             test_no_device_fails_loudly(va);
         } else if (mode == "--gpu") {
