@@ -214,6 +214,36 @@ int32_t ixr_scan_filter_run(int32_t device, const ixr_scan_filter_desc* descs, i
                             uint64_t decoded_bytes, const void* values, uint64_t values_bytes, void* d_bitmaps,
                             uint64_t bitmap_bytes, int32_t* results, void* stream);
 
+/* ---- the rows a bitmap picks ----------------------------------------------------------------------------------------
+ * The batch form of DataPack.foreach(BitMap position, XxxSetter)
+ * (indexr-segment/src/main/java/io/indexr/segment/pack/DataPack.java: int :273-306, long :324-357, float :375-408,
+ * double :426-459, BytePiece :708-762): what a reader does with the bitmap a predicate produced.  The setter is called
+ * for every set bit below objCount in rising row order (BitMap.ALL: every row), and the return value is the number of
+ * calls; here the calls' arguments are laid out at dst_off, n = obj_count:
+ *   numbers   int32 rowId[n] | value[n], the values starting at the next multiple of 8 after 4 * n
+ *   strings   int32 rowId[n] | int32 arrayOffset[n] | int32 arrayLength[n] | the picked rows' bytes one after the other
+ *             (arrayOffset counts from the start of those bytes)
+ * of which the first counts[i] entries of each array are written.  Input: a decoded-pack arena as ixr_plan_run leaves it
+ * and a bitmap arena as the two filter calls leave it (bits at or above obj_count are ignored, as the reference's loop
+ * stops there).  dst_off must be a multiple of IXR_ARENA_ALIGN, with ixr_select_bound(desc) bytes behind it.  counts[i]
+ * is the number of picked rows, IXR_ERR_DATA_CORRUPTED for string offsets that leave the pack, IXR_ERR_INVALID_ARGUMENT
+ * for a data_size too small for obj_count rows.  The call synchronises with `stream`.  Returns the number of packs with
+ * a negative count, or a negative library error.
+ */
+typedef struct ixr_select_desc {
+    uint64_t src_off;    /* decoded pack inside the decoded arena, multiple of 8 */
+    uint64_t dst_off;    /* output inside the select arena, multiple of IXR_ARENA_ALIGN */
+    uint64_t bitmap_off; /* the pack's IXR_BITMAP_BYTES inside the bitmap arena, multiple of 8; unused when all = 1 */
+    int32_t  data_type;  /* IXR_INT ... IXR_STRING */
+    int32_t  obj_count;  /* rows in the pack */
+    int32_t  data_size;  /* dpn.dataSize of the pack */
+    int32_t  all;        /* 1: position == BitMap.ALL; 0: read the bitmap */
+} ixr_select_desc;
+uint64_t ixr_select_bound(const ixr_select_desc* desc);
+int32_t  ixr_select_run(int32_t device, const ixr_select_desc* descs, int32_t n, const void* d_decoded,
+                        uint64_t decoded_bytes, const void* d_bitmaps, uint64_t bitmap_bytes, void* d_out,
+                        uint64_t out_bytes, int32_t* counts, void* stream);
+
 /* ---- engine hand-back on device -----------------------------------------------------------------------------------
  * The step right after the decode in the Spark reader: decoded pack -> column vector contents for rows
  * [row_offset, row_offset + row_count), DefaultPackReader.readByCopy / readBySet

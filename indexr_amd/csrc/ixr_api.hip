@@ -768,6 +768,63 @@ extern "C" int32_t ixr_handback_run(int32_t device, const ixr_handback_desc* des
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// rows picked by a bitmap (DataPack.foreach(BitMap position, XxxSetter), DataPack.java:273-306, 708-762)
+// ---------------------------------------------------------------------------------------------------------------
+static_assert(sizeof(SelectDesc) == sizeof(ixr_select_desc), "device and ABI descriptor layouts must match");
+
+extern "C" uint64_t ixr_select_bound(const ixr_select_desc* d) {
+    if (!d || d->obj_count < 0 || d->data_size < 0) return 0;
+    const uint64_t c = (uint64_t)d->obj_count;
+    if (d->data_type == IXR_STRING) {
+        const uint64_t index = 4ull * (c + 1);
+        const uint64_t body = (uint64_t)d->data_size > index ? (uint64_t)d->data_size - index : 0;
+        return align16(12 * c + body);
+    }
+    const uint64_t w = (d->data_type == IXR_INT || d->data_type == IXR_FLOAT) ? 4 : 8;
+    return align16(((4 * c + 7) & ~7ull) + w * c);
+}
+
+extern "C" int32_t ixr_select_run(int32_t device, const ixr_select_desc* descs, int32_t n, const void* d_decoded,
+                                  uint64_t decoded_bytes, const void* d_bitmaps, uint64_t bitmap_bytes, void* d_out,
+                                  uint64_t out_bytes, int32_t* counts, void* stream) {
+    if (ixr_init(device) != 0) return IXR_ERR_NO_DEVICE;
+    if (!descs || n <= 0 || !d_decoded || !d_out || !counts) return fail(IXR_ERR_INVALID_ARGUMENT, "null argument or no descriptors");
+    if (((uintptr_t)d_decoded & 15) || ((uintptr_t)d_out & 15) || ((uintptr_t)d_bitmaps & 7))
+        return fail(IXR_ERR_INVALID_ARGUMENT, "misaligned device pointer");
+    for (int i = 0; i < n; i++) {
+        const ixr_select_desc& d = descs[i];
+        if (d.data_type < IXR_INT || d.data_type > IXR_STRING || d.obj_count <= 0 || d.obj_count > IXR_PACK_MAX_ROWS || d.data_size < 0 ||
+            (d.src_off % 8) || (d.dst_off % IXR_ARENA_ALIGN) || (d.all != 0 && d.all != 1))
+            return fail(IXR_ERR_INVALID_ARGUMENT, "select descriptor %d: bad type, sizes or alignment", i);
+        if (d.src_off + (uint64_t)d.data_size > decoded_bytes) return fail(IXR_ERR_INVALID_ARGUMENT, "select descriptor %d: pack outside the decoded arena", i);
+        if (d.dst_off + ixr_select_bound(&d) > out_bytes) return fail(IXR_ERR_INVALID_ARGUMENT, "select descriptor %d: output outside the arena", i);
+        if (!d.all) {
+            if (!d_bitmaps || (d.bitmap_off % 8) || d.bitmap_off + IXR_BITMAP_BYTES > bitmap_bytes)
+                return fail(IXR_ERR_INVALID_ARGUMENT, "select descriptor %d: bitmap outside the bitmap arena", i);
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    SelectDesc* dd = nullptr;
+    int32_t* dc = nullptr;
+    int32_t rc = 0;
+    if (hipMalloc((void**)&dd, sizeof(SelectDesc) * (size_t)n) != hipSuccess || hipMalloc((void**)&dc, sizeof(int32_t) * (size_t)n) != hipSuccess)
+        rc = fail(IXR_ERR_OUT_OF_MEMORY, "hipMalloc failed");
+    if (!rc && hipMemcpyAsync(dd, descs, sizeof(SelectDesc) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess) rc = fail(IXR_ERR_HIP, "H2D failed");
+    if (!rc) {
+        launch_select(st, dd, n, (const uint8_t*)d_decoded, (const uint8_t*)d_bitmaps, (uint8_t*)d_out, dc);
+        if (hipGetLastError() != hipSuccess) rc = fail(IXR_ERR_HIP, "kernel launch failed");
+    }
+    if (!rc && hipMemcpyAsync(counts, dc, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st) != hipSuccess) rc = fail(IXR_ERR_HIP, "D2H failed");
+    if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = fail(IXR_ERR_HIP, "stream synchronise failed");
+    if (dd) (void)hipFree(dd);
+    if (dc) (void)hipFree(dc);
+    if (rc) return rc;
+    int bad = 0;
+    for (int i = 0; i < n; i++) bad += counts[i] < 0;
+    return bad;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // predicate evaluation on dictionary ids (ExtIndex_DictBits.java:33-200)
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" int32_t ixr_plan_run_filter(ixr_plan* pl, const void* d_in, uint64_t in_bytes, const ixr_filter_desc* filters,

@@ -2175,6 +2175,97 @@ __global__ __launch_bounds__(256) void k_scan_filter(const ScanFilterDesc* __res
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// k_select: the rows of a decoded pack that a bitmap picks, in row order (DataPack.foreach(BitMap position, XxxSetter),
+// DataPack.java:273-306, 324-357, 375-408, 426-459, 708-762: every set bit below objCount; BitMap.ALL is every row).
+// One workgroup of 1024 threads per descriptor; a tile of 1024 rows per round, positions by a workgroup scan.
+//   numbers   int32 rowId[n] | value[n] (8-byte values start at a multiple of 8)
+//   strings   int32 rowId[n] | int32 arrayOffset[n] | int32 arrayLength[n] | the picked rows' bytes one after the other
+// counts[d] = number of picked rows, or a negative error.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename U>
+__device__ __forceinline__ U wg1024_excl_scan(U v, U* s_w, U* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const U incl = wave_incl_scan<U>(v);
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        const U x = lane < 16 ? s_w[lane] : (U)0;
+        const U xi = wave_incl_scan<U>(x);
+        if (lane < 16) s_w[lane] = xi - x;
+        if (lane == 15) s_w[16] = xi;
+    }
+    __syncthreads();
+    const U r = s_w[wave] + incl - v;
+    *total = s_w[16];
+    __syncthreads();
+    return r;
+}
+__global__ __launch_bounds__(1024) void k_select(const SelectDesc* __restrict__ descs, const uint8_t* __restrict__ decoded,
+                                                 const uint8_t* __restrict__ bitmaps, uint8_t* __restrict__ out, int32_t* __restrict__ counts) {
+    __shared__ uint32_t s_w[17];
+    __shared__ unsigned long long s_wb[17];  // byte positions: 1024 rows of up to 2^31 bytes each
+    __shared__ int s_bad;
+    const SelectDesc D = descs[blockIdx.x];
+    const int tid = threadIdx.x;
+    const uint32_t n = (uint32_t)D.obj_count;
+    const uint8_t* src = decoded + D.src_off;
+    const unsigned long long* bm = (const unsigned long long*)(bitmaps + D.bitmap_off);
+    uint8_t* dst = out + D.dst_off;
+    int32_t* row_id = (int32_t*)dst;
+    const int dt = D.data_type;
+    const uint32_t w = (dt == 1 || dt == 3) ? 4u : 8u;
+    if (dt == 5 ? 4ull * (n + 1) > (uint64_t)D.data_size : (uint64_t)n * w > (uint64_t)D.data_size) {
+        if (tid == 0) counts[blockIdx.x] = -1000;
+        return;
+    }
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    const int32_t* off = (const int32_t*)src;
+    const uint8_t* body = src + 4ull * (n + 1);
+    const int64_t body_cap = (int64_t)D.data_size - 4ll * (n + 1);
+    int32_t* aoff = row_id + n;
+    int32_t* alen = aoff + n;
+    uint8_t* bytes = dst + 12ull * n;
+    uint8_t* vals = dst + ((4ull * n + 7) & ~7ull);
+    uint32_t count = 0;
+    unsigned long long byte_pos = 0;
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t r = base + tid;
+        bool pick = r < n && (D.all || ((bm[r >> 6] >> (r & 63)) & 1ull));
+        int32_t a = 0, len = 0;
+        if (pick && dt == 5) {
+            a = off[r];
+            const int32_t b = off[r + 1];
+            if (a < 0 || b < a || (int64_t)b > body_cap) { s_bad = 1; pick = false; }
+            len = b - a;
+        }
+        uint32_t tot;
+        const uint32_t pos = count + wg1024_excl_scan<uint32_t>(pick ? 1u : 0u, s_w, &tot);
+        count += tot;
+        if (dt == 5) {
+            unsigned long long btot;
+            const unsigned long long bp = byte_pos + wg1024_excl_scan<unsigned long long>(pick ? (unsigned long long)len : 0ull, s_wb, &btot);
+            byte_pos += btot;
+            // rows whose offsets step backwards in between can overlap: more bytes than the pack's body holds do not fit
+            if (pick && bp + (unsigned long long)len > (unsigned long long)body_cap) { s_bad = 1; pick = false; }
+            if (pick) {
+                row_id[pos] = (int32_t)r;
+                aoff[pos] = (int32_t)bp;
+                alen[pos] = len;
+                const uint8_t* sp = body + a;
+                for (int32_t k = 0; k < len; k++) bytes[bp + k] = sp[k];
+            }
+        } else if (pick) {
+            row_id[pos] = (int32_t)r;
+            if (w == 4) ((uint32_t*)vals)[pos] = ((const uint32_t*)src)[r];
+            else ((uint64_t*)vals)[pos] = ((const uint64_t*)src)[r];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) counts[blockIdx.x] = s_bad ? E_CORRUPT : (int32_t)count;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // k_handback: decoded pack -> Spark column vector contents (DefaultPackReader.readByCopy / readBySet,
 // DefaultPackReader.java:164-241).  grid = (blocks per descriptor, descriptors); elementwise, memory bound.
 // ---------------------------------------------------------------------------------------------------------------
@@ -2377,6 +2468,11 @@ void launch_scan_filter(hipStream_t stream, const ScanFilterDesc* descs, int cou
                         unsigned long long* bitmaps, int32_t* results) {
     if (count <= 0) return;
     hipLaunchKernelGGL(k_scan_filter, dim3(IXR_PACK_TILES / 4, count), dim3(256), 0, stream, descs, decoded, values, bitmaps, results);
+}
+void launch_select(hipStream_t stream, const SelectDesc* descs, int count, const uint8_t* decoded, const uint8_t* bitmaps, uint8_t* out,
+                   int32_t* counts) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_select, dim3(count), dim3(1024), 0, stream, descs, decoded, bitmaps, out, counts);
 }
 void launch_handback(hipStream_t stream, const HandbackDesc* descs, int count, const uint8_t* decoded, uint8_t* out, int32_t* status) {
     if (count <= 0) return;

@@ -64,6 +64,14 @@ struct ScanFilterDesc {
 void launch_scan_filter(hipStream_t stream, const ScanFilterDesc* descs, int count, const uint8_t* decoded, const uint8_t* values,
                         unsigned long long* bitmaps, int32_t* results);
 
+// rows of decoded packs picked by a bitmap (DataPack.foreach(BitMap, ...)); descs / counts are device arrays
+struct SelectDesc {
+    uint64_t src_off, dst_off, bitmap_off;
+    int32_t data_type, obj_count, data_size, all;
+};
+void launch_select(hipStream_t stream, const SelectDesc* descs, int count, const uint8_t* decoded, const uint8_t* bitmaps, uint8_t* out,
+                   int32_t* counts);
+
 // engine hand-back (decoded pack -> column vector contents); descs / status are device arrays
 struct HandbackDesc {
     uint64_t src_off, dst_off;

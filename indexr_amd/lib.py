@@ -66,6 +66,12 @@ class ScanFilterDesc(C.Structure):
                 ("data_size", C.c_int32), ("op", C.c_int32), ("n_values", C.c_int32), ("reserved", C.c_int32)]
 
 
+class SelectDesc(C.Structure):
+    """ixr_select_desc: the rows of one decoded pack that a bitmap picks (DataPack.foreach(BitMap, XxxSetter), DataPack.java:273-306)"""
+    _fields_ = [("src_off", C.c_uint64), ("dst_off", C.c_uint64), ("bitmap_off", C.c_uint64), ("data_type", C.c_int32),
+                ("obj_count", C.c_int32), ("data_size", C.c_int32), ("all", C.c_int32)]
+
+
 class EncodeDesc(C.Structure):
     """ixr_encode_desc: one decoded numeric pack to compress on the device (PackCompressor_VLT.compress)"""
     _fields_ = [("src_off", C.c_uint64), ("dst_off", C.c_uint64), ("data_type", C.c_int32), ("is_indexed", C.c_int32),
@@ -112,6 +118,8 @@ _sig = {
     "ixr_compress_bound": (_i32, [_i32, _i32]),
     "ixr_plan_run_filter": (_i32, [_vp, _vp, _u64, C.POINTER(FilterDesc), _vp, _u64, _vp, _u64, C.POINTER(_i32), _vp]),
     "ixr_scan_filter_run": (_i32, [_i32, C.POINTER(ScanFilterDesc), _i32, _vp, _u64, _vp, _u64, _vp, _u64, C.POINTER(_i32), _vp]),
+    "ixr_select_bound": (_u64, [C.POINTER(SelectDesc)]),
+    "ixr_select_run": (_i32, [_i32, C.POINTER(SelectDesc), _i32, _vp, _u64, _vp, _u64, _vp, _u64, C.POINTER(_i32), _vp]),
     "ixr_encode_run": (_i32, [_i32, C.POINTER(EncodeDesc), _i32, _vp, _u64, _vp, _u64, _u64, _vp]),
     "ixr_handback_bound": (_u64, [C.POINTER(HandbackDesc)]),
     "ixr_handback_run": (_i32, [_i32, C.POINTER(HandbackDesc), _i32, _vp, _u64, _vp, _u64, C.POINTER(_i32), _vp]),
@@ -335,6 +343,17 @@ def scan_filter_run(descs, d_decoded, decoded_bytes, values, d_bitmaps, bitmap_b
     if bad < 0:
         raise IxrError(bad, "ixr_scan_filter_run")
     return np.frombuffer(res, dtype=np.int32).copy(), bad
+
+
+def select_run(descs, d_decoded, decoded_bytes, d_bitmaps, bitmap_bytes, d_out, out_bytes, device=0, stream=None):
+    """ixr_select_run: -> (picked rows per descriptor, number of descriptors with a negative count)"""
+    n = len(descs)
+    arr = (SelectDesc * n)(*descs)
+    cnt = (_i32 * n)()
+    bad = lib.ixr_select_run(device, arr, n, d_decoded, decoded_bytes, d_bitmaps, bitmap_bytes, d_out, out_bytes, cnt, stream)
+    if bad < 0:
+        raise IxrError(bad, "ixr_select_run")
+    return np.frombuffer(cnt, dtype=np.int32).copy(), bad
 
 
 def encode_run(descs, d_data, data_bytes, d_out, out_bytes, device=0, scratch_budget=0, stream=None):

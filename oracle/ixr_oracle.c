@@ -1354,6 +1354,53 @@ int ixo_scan_filter(int data_type, int n, const uint8_t* data, int data_size, in
     return any ? 2 : 0;
 }
 
+/* DataPack.foreach(BitMap position, XxxSetter) (indexr-segment/src/main/java/io/indexr/segment/pack/DataPack.java: int
+ * :273-306, long :324-357, float :375-408, double :426-459, BytePiece :708-762): position == BitMap.ALL (here bitmap ==
+ * NULL) visits every row; otherwise DirectBitMapIterator.nextSetBit hands out the set bits in rising order and the loop
+ * stops at the first index >= objCount.  Every setter.set(index, value) call is recorded: row_ids[k] = index; numbers:
+ * the value's bytes at values + k * width; strings: str_off[k] / str_len[k] and the bytes appended to values.  Returns
+ * the number of calls (the reference's return value). */
+int ixo_select(int data_type, int n, const uint8_t* data, int data_size, const uint64_t* bitmap, int32_t* row_ids,
+               uint8_t* values, int32_t* str_off, int32_t* str_len) {
+    if (n < 0 || data_type < IXO_INT || data_type > IXO_STRING) return -1000;
+    const int w = (data_type == IXO_INT || data_type == IXO_FLOAT) ? 4 : 8;
+    if (data_type == IXO_STRING ? 4 * ((int64_t)n + 1) > data_size : (int64_t)n * w > data_size) return -1000;
+    int count = 0;
+    int32_t bytes = 0;
+    int word = 0;
+    uint64_t cur = bitmap ? bitmap[0] : 0;
+    int next_all = 0;
+    for (;;) {
+        int index;
+        if (!bitmap) {
+            if (next_all >= n) break;
+            index = next_all++;
+        } else {
+            while (cur == 0 && word < 1023) cur = bitmap[++word];
+            if (cur == 0) break;  /* NO_MORE */
+            index = word * 64 + __builtin_ctzll(cur);
+            cur &= cur - 1;
+            if (index >= n) break;
+        }
+        row_ids[count] = index;
+        if (data_type == IXO_STRING) {
+            const int32_t a = ld32(data + 4 * (size_t)index), b = ld32(data + 4 * (size_t)(index + 1));
+            if (a < 0 || b < a || 4 * ((int64_t)n + 1) + b > data_size) return IXO_DATA_CORRUPTED;
+            /* the recorded bytes are bounded by the pack's body; overlapping rows (offsets stepping backwards between
+             * two picked rows) that exceed it are reported rather than recorded */
+            if (4 * ((int64_t)n + 1) + bytes + (b - a) > data_size) return IXO_DATA_CORRUPTED;
+            memcpy(values + bytes, data + 4 * ((size_t)n + 1) + a, (size_t)(b - a));
+            str_off[count] = bytes;
+            str_len[count] = b - a;
+            bytes += b - a;
+        } else {
+            memcpy(values + (size_t)count * w, data + (size_t)index * w, (size_t)w);
+        }
+        count++;
+    }
+    return count;
+}
+
 /* DataPackCreator_VLT.from (indexr-vlt-segment/.../segment/pack/DataPackCreator_VLT.java:21-163): dpn.minValue / maxValue /
  * sum of a numeric pack.  java.lang.Math.min / max on float and double: a NaN first argument is returned, -0.0 is below
  * 0.0, otherwise <= / >=. */

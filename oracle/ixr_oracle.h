@@ -107,6 +107,13 @@ int ixo_filter(int data_type, int encode_type, int n, const uint8_t* pack, int p
 int ixo_scan_filter(int data_type, int n, const uint8_t* data, int data_size, int op, int n_values,
                     const int64_t* num_values, const uint8_t* str_values, uint64_t* bitmap);
 
+/* DataPack.foreach(BitMap position, XxxSetter) (indexr-segment/.../segment/pack/DataPack.java:273-306, 324-357, 375-408,
+ * 426-459, 708-762): the setter calls for the set bits below n in rising order; bitmap == NULL is BitMap.ALL.  row_ids[k],
+ * and per call either the value at values + k * width or str_off[k] / str_len[k] into the bytes appended to values.
+ * Returns the number of calls, IXO_DATA_CORRUPTED for string offsets that leave the pack, -1000 for bad arguments. */
+int ixo_select(int data_type, int n, const uint8_t* data, int data_size, const uint64_t* bitmap, int32_t* row_ids,
+               uint8_t* values, int32_t* str_off, int32_t* str_len);
+
 /* DataPackCreator_VLT.from (indexr-vlt-segment/.../segment/pack/DataPackCreator_VLT.java:21-163): dpn.minValue, maxValue
  * and sum of a numeric pack (floats: Math.min / Math.max fold, float / double running sum, raw bits of the widened value). */
 int ixo_pack_stats(int data_type, int n, const uint8_t* data, int64_t* min_value, int64_t* max_value, int64_t* sum);

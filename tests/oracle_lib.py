@@ -61,6 +61,8 @@ for name, res, args in [
     ("ixo_scan_filter", C.c_int, [C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), _u8p, C.POINTER(C.c_uint64)]),
     ("ixo_like", C.c_int, [_u8p, C.c_int, _u8p, C.c_int]),
     ("ixo_pack_stats", C.c_int, [C.c_int, C.c_int, _u8p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("ixo_select", C.c_int, [C.c_int, C.c_int, _u8p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_int32), _u8p,
+                             C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("ixo_handback", C.c_int, [C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]),
 ]:
     fn = getattr(lib, name)
@@ -188,3 +190,28 @@ def pack_stats(data, data_type, n):
     if r:
         raise RuntimeError("ixo_pack_stats: %d" % r)
     return a.value, b.value, c.value
+
+
+def select_pack(data, data_type, n, bitmap=None):
+    """DataPack.foreach(BitMap, setter) on one decoded pack; bitmap None = BitMap.ALL.
+    -> (count or error, row ids int32[count], values: np array of the pack's type, or list of bytes for strings)"""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    ids = np.zeros(max(n, 1), dtype=np.int32)
+    vals = np.zeros(len(data) + 8, dtype=np.uint8)
+    so = np.zeros(max(n, 1), dtype=np.int32)
+    sl = np.zeros(max(n, 1), dtype=np.int32)
+    i32p = C.POINTER(C.c_int32)
+    bp = None
+    if bitmap is not None:
+        bitmap = np.ascontiguousarray(bitmap, dtype=np.uint64)
+        assert len(bitmap) == 1024
+        bp = bitmap.ctypes.data_as(C.POINTER(C.c_uint64))
+    r = lib.ixo_select(data_type, n, _p(data), len(data), bp, ids.ctypes.data_as(i32p), _p(vals), so.ctypes.data_as(i32p),
+                       sl.ctypes.data_as(i32p))
+    if r < 0:
+        return r, None, None
+    if data_type == STRING:
+        body = vals.tobytes()
+        return r, ids[:r].copy(), [body[so[k]:so[k] + sl[k]] for k in range(r)]
+    dt = {INT: "<i4", LONG: "<i8", FLOAT: "<f4", DOUBLE: "<f8"}[data_type]
+    return r, ids[:r].copy(), vals[:r * np.dtype(dt).itemsize].view(dt).copy()

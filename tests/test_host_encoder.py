@@ -140,3 +140,6 @@ def test_neighbouring_entry_points_fail_loudly_without_gpu():
     with pytest.raises(L.IxrError) as e:
         L.handback_run([L.HandbackDesc(0, 0, 10, 40, L.SQL_INT, 0, 10, 0)], fake, 64, fake, 64)
     assert e.value.code in (L.ERR_NO_DEVICE, L.ERR_HIP)
+    with pytest.raises(L.IxrError) as e:
+        L.select_run([L.SelectDesc(0, 0, 0, L.INT, 10, 40, 0)], fake, 64, fake, 8192, fake, 256)
+    assert e.value.code in (L.ERR_NO_DEVICE, L.ERR_HIP)
