@@ -694,63 +694,86 @@ __global__ __launch_bounds__(256) void k_delta(const DevPack* __restrict__ packs
     __shared__ uint32_t s_win[12][256];  // per thread: the up to 48 bytes its V values are packed in, dword k at [k][tid]
     U carry = (U)s.first;
     int buf = 0;
-    // unpack the V values of this thread for the chunk starting at c0 (minDelta already added); zeros past the end.
-    // The V values sit in V * bw consecutive bits: they are fetched with one to three 16-byte loads (instead of two or three
-    // dword loads per value), parked in the thread's LDS column and picked out of it at their bit offsets.
-    auto unpack = [&](uint32_t c0, U (&d)[V]) {
+    // A chunk's values take two dependent round trips (the mini-block index, then the packed bits) and the workgroup
+    // walks the chunks one after the other, so the trips are taken ahead of time: the index entries three chunks ahead
+    // and the packed bits two chunks ahead are requested before a chunk is scanned and stored, and are in registers by
+    // the time their chunk is unpacked.
+    struct Head { uint32_t hdr; U md; };     // stage 1: mini-block record and block minimum of this thread's values
+    struct Bits { uint4 w[3]; uint32_t sh, bw; U md; };  // stage 2: the up to 48 bytes the V values are packed in
+    auto head_of = [&](uint32_t c0) {
+        const uint32_t i0 = c0 + V * tid;
+        Head h{0u, (U)0};
+        if (i0 < n) { h.hdr = mb[i0 >> 5]; h.md = (U)min_delta[i0 >> 7]; }
+        return h;
+    };
+    // The V values sit in V * bw consecutive bits: they are fetched with one to three 16-byte loads (instead of two or
+    // three dword loads per value)
+    auto bits_of = [&](uint32_t c0, const Head& h) {
+        const uint32_t i0 = c0 + V * tid;
+        Bits b;
+        b.w[0] = b.w[1] = b.w[2] = make_uint4(0, 0, 0, 0);
+        b.bw = h.hdr >> 24;
+        b.md = h.md;
+        b.sh = 0;
+        if (i0 < n && b.bw) {
+            const uint32_t bit = (i0 & 31) * b.bw;
+            const uintptr_t a = (uintptr_t)(base + (h.hdr & 0xFFFFFFu) + (bit >> 3));
+            const uint8_t* al = (const uint8_t*)(a & ~(uintptr_t)3);
+            b.sh = ((uint32_t)(a & 3) << 3) + (bit & 7);  // 0..31
+            // bits of this thread's values that exist: a load reaches less than 16 bytes past them (the arena's slack)
+            const uint32_t nbits = b.sh + min((uint32_t)V, n - i0) * b.bw;  // <= 31 + 256
+            __builtin_memcpy(&b.w[0], al, 16);
+            if (nbits > 128) __builtin_memcpy(&b.w[1], al + 16, 16);
+            if (nbits > 256) __builtin_memcpy(&b.w[2], al + 32, 16);
+        }
+        return b;
+    };
+    // stage 3: park the bytes in the thread's LDS column and pick the values out of it at their bit offsets (minDelta
+    // added); zeros past the end
+    auto unpack = [&](uint32_t c0, const Bits& b, U (&d)[V]) {
         const uint32_t i0 = c0 + V * tid;
 #pragma unroll
         for (int q = 0; q < V; q++) d[q] = 0;
-        if (i0 < n) {
-            const uint32_t hdr = mb[i0 >> 5];
-            const uint32_t bw = hdr >> 24;
-            const U md = (U)min_delta[i0 >> 7];
-            if (bw == 0) {
+        if (i0 >= n) return;
+        const uint32_t bw = b.bw;
+        const U md = b.md;
+        if (bw == 0) {
 #pragma unroll
-                for (int q = 0; q < V; q++)
-                    if (i0 + q < n) d[q] = md;
-                return;
-            }
-            const uint32_t bit = (i0 & 31) * bw;
-            const uintptr_t a = (uintptr_t)(base + (hdr & 0xFFFFFFu) + (bit >> 3));
-            const uint8_t* al = (const uint8_t*)(a & ~(uintptr_t)3);
-            const uint32_t sh = ((uint32_t)(a & 3) << 3) + (bit & 7);  // 0..31
-            // bits of this thread's values that exist: a load reaches less than 16 bytes past them (the arena's slack)
-            const uint32_t nbits = sh + min((uint32_t)V, n - i0) * bw;  // <= 31 + 256
-            uint4 w[3];
-            __builtin_memcpy(&w[0], al, 16);
-            w[1] = w[2] = make_uint4(0, 0, 0, 0);
-            if (nbits > 128) __builtin_memcpy(&w[1], al + 16, 16);
-            if (nbits > 256) __builtin_memcpy(&w[2], al + 32, 16);
+            for (int q = 0; q < V; q++)
+                if (i0 + q < n) d[q] = md;
+            return;
+        }
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                s_win[4 * k + 0][tid] = w[k].x; s_win[4 * k + 1][tid] = w[k].y;
-                s_win[4 * k + 2][tid] = w[k].z; s_win[4 * k + 3][tid] = w[k].w;
-            }
+        for (int k = 0; k < 3; k++) {
+            s_win[4 * k + 0][tid] = b.w[k].x; s_win[4 * k + 1][tid] = b.w[k].y;
+            s_win[4 * k + 2][tid] = b.w[k].z; s_win[4 * k + 3][tid] = b.w[k].w;
+        }
 #pragma unroll
-            for (int q = 0; q < V; q++) {
-                if (i0 + q < n) {
-                    const uint32_t off = sh + q * bw, k = off >> 5, r = off & 31;
-                    const uint64_t lo = (uint64_t)s_win[k][tid] | ((uint64_t)s_win[k + 1][tid] << 32);
-                    if constexpr (sizeof(U) == 4) {
-                        const uint32_t v = (uint32_t)(lo >> r);
-                        d[q] = (bw >= 32 ? v : (v & ((1u << bw) - 1u))) + md;
-                    } else {
-                        const uint64_t hi = s_win[k + 2][tid];
-                        const uint64_t v = r ? ((lo >> r) | (hi << (64 - r))) : lo;
-                        d[q] = (bw >= 64 ? v : (v & ((1ull << bw) - 1ull))) + md;
-                    }
+        for (int q = 0; q < V; q++) {
+            if (i0 + q < n) {
+                const uint32_t off = b.sh + q * bw, k = off >> 5, r = off & 31;
+                const uint64_t lo = (uint64_t)s_win[k][tid] | ((uint64_t)s_win[k + 1][tid] << 32);
+                if constexpr (sizeof(U) == 4) {
+                    const uint32_t v = (uint32_t)(lo >> r);
+                    d[q] = (bw >= 32 ? v : (v & ((1u << bw) - 1u))) + md;
+                } else {
+                    const uint64_t hi = s_win[k + 2][tid];
+                    const uint64_t v = r ? ((lo >> r) | (hi << (64 - r))) : lo;
+                    d[q] = (bw >= 64 ? v : (v & ((1ull << bw) - 1ull))) + md;
                 }
             }
         }
     };
-    U d[V];
-    unpack(0, d);
+    Bits b0 = bits_of(0, head_of(0));
+    Bits b1 = bits_of(kChunk, head_of(kChunk));
+    Head h2 = head_of(2 * kChunk);
     for (uint32_t c0 = 0; c0 < n; c0 += kChunk, buf ^= 1) {
         const uint32_t i0 = c0 + V * tid;
-        // software pipeline: the next chunk's loads are issued before this chunk's scan and barrier
-        U e[V];
-        unpack(c0 + kChunk, e);
+        U d[V];
+        unpack(c0, b0, d);
+        b0 = b1;
+        b1 = bits_of(c0 + 2 * kChunk, h2);
+        h2 = head_of(c0 + 3 * kChunk);
 #pragma unroll
         for (int q = 1; q < V; q++) d[q] += d[q - 1];
         const U incl = wave_incl_scan<U>(d[V - 1]);
@@ -777,8 +800,6 @@ __global__ __launch_bounds__(256) void k_delta(const DevPack* __restrict__ packs
                 if (i0 + q < n) dst[i0 + q] = d[q] + pre;
         }
         carry += w0 + w1 + w2 + w3;
-#pragma unroll
-        for (int q = 0; q < V; q++) d[q] = e[q];
     }
 }
 
