@@ -472,36 +472,95 @@ struct Walker {
 
 
 // Walk one DELTA stream (DeltaCodec.decodeInts/decodeLongs framing, DeltaCodec.java:100-141, 204-245) and write its index.
+// A block is a varint and four width bytes, each behind the mini-block the previous byte sizes: five dependent memory
+// round trips.  Streams mostly keep one width for a whole block, so the walk fetches a block's header as 16 bytes (the
+// varint and the first width byte), and in the same round trip the three bytes where the other width bytes are if every
+// mini-block has the first one's width, plus the 16 bytes where the next block then starts.  A byte is used only when
+// the walk arrives at exactly the position it was fetched from; any other position is read again.  One round trip per
+// block when the guess holds, never more than before when it does not.
+__device__ __forceinline__ void ld16g(const uint8_t* p, uint64_t& lo, uint64_t& hi) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
+    hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+}
+__device__ __forceinline__ uint32_t byte_of(uint64_t lo, uint64_t hi, uint32_t i) {
+    return (uint32_t)((i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8))) & 0xFFu);
+}
 __device__ int32_t lane_walk_delta(const uint8_t* base, uint32_t pack_size, uint32_t off, uint32_t n, int width,
                               int64_t* min_delta, uint32_t* mb, int64_t* first_out, bool write) {
-    Walker w{base, off, pack_size, 0};
     if (off + 4 > pack_size) return E_CORRUPT;
-    int32_t len = (int32_t)ld32u(base + off);
+    const int32_t len = (int32_t)ld32u(base + off);
     if (len < 0 || (uint64_t)off + 4 + (uint64_t)len > pack_size) return E_CORRUPT;
-    w.pos = off + 4;
-    w.end = off + 4 + (uint32_t)len;
-    const int vb = width == 32 ? 5 : 10;
-    uint64_t raw = w.uvarint(vb);
-    *first_out = width == 32 ? unzigzag32(raw) : unzigzag64(raw);
-    uint32_t nb = (n + kBlock - 1) / kBlock;
-    for (uint32_t b = 0; b < nb && !w.err; b++) {
-        raw = w.uvarint(vb);
-        int64_t md = width == 32 ? unzigzag32(raw) : unzigzag64(raw);
-        if (write) min_delta[b] = md;
-        uint32_t cnt = min((uint32_t)kBlock, n - b * kBlock);
-        for (uint32_t m = 0; m * kMini < cnt; m++) {
-            uint32_t c = min((uint32_t)kMini, cnt - m * kMini);
-            uint32_t bw = w.u8();
-            if (bw > (uint32_t)width) w.err = E_CORRUPT;
-            if (w.err) break;
-            if (w.pos >= (1u << 24)) { w.err = E_CORRUPT; break; }
-            if (write) mb[b * 4 + m] = w.pos | (bw << 24);
-            w.pos += ((c + 7) >> 3) * bw;
-            if (w.pos > w.end) { w.err = E_CORRUPT; break; }
+    uint32_t pos = off + 4;
+    const uint32_t end = off + 4 + (uint32_t)len;
+    const uint32_t vb = width == 32 ? 5 : 10;
+    // VarInteger.readUnsignedVarInt / readUnsignedVarLong (VarInteger.java:68-96) out of a 16-byte window that holds
+    // `avail` bytes of the stream; 0 bytes consumed = the stream ended inside the varint or it has more than vb bytes
+    auto varint = [&](uint64_t lo, uint64_t hi, uint32_t avail, uint32_t& used) {
+        uint64_t v = 0;
+        used = 0;
+        for (uint32_t i = 0; i < vb && i < avail; i++) {
+            const uint32_t b = byte_of(lo, hi, i);
+            v |= (uint64_t)(b & 0x7F) << (7 * i);
+            if (!(b & 0x80)) { used = i + 1; break; }
         }
+        return v;
+    };
+    uint64_t lo, hi;
+    uint32_t used;
+    if (pos >= end) return E_CORRUPT;
+    ld16g(base + pos, lo, hi);
+    uint64_t raw = varint(lo, hi, min(16u, end - pos), used);
+    if (!used) return E_CORRUPT;
+    pos += used;
+    *first_out = width == 32 ? unzigzag32(raw) : unzigzag64(raw);
+    const uint32_t nb = (n + kBlock - 1) / kBlock;
+    bool have = false;  // lo / hi already hold the 16 bytes at pos
+    for (uint32_t b = 0; b < nb; b++) {
+        if (pos >= end) return E_CORRUPT;
+        if (!have) ld16g(base + pos, lo, hi);
+        have = false;
+        raw = varint(lo, hi, min(16u, end - pos), used);
+        if (!used) return E_CORRUPT;
+        if (write) min_delta[b] = width == 32 ? unzigzag32(raw) : unzigzag64(raw);
+        pos += used;
+        const uint32_t cnt = min((uint32_t)kBlock, n - b * kBlock);
+        // first mini-block: its width byte follows the varint inside the window (used <= 10)
+        if (pos >= end) return E_CORRUPT;
+        uint32_t bw = byte_of(lo, hi, used);
+        pos++;
+        if (bw > (uint32_t)width || pos >= (1u << 24)) return E_CORRUPT;
+        if (write) mb[b * 4] = pos | (bw << 24);
+        pos += ((min((uint32_t)kMini, cnt) + 7) >> 3) * bw;
+        if (pos > end) return E_CORRUPT;
+        // the guess: the other mini-blocks are full and as wide as the first
+        const uint32_t stride = 1 + (kMini / 8) * bw;
+        const uint32_t p1 = pos, p4 = pos + 3 * stride;
+        uint32_t spec[3] = {0, 0, 0};
+        uint64_t nlo = 0, nhi = 0;
+        const bool full = cnt == (uint32_t)kBlock;
+        if (full) {
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                if (p1 + k * stride < end) spec[k] = base[p1 + k * stride];
+            if (p4 < end) ld16g(base + p4, nlo, nhi);
+        }
+#pragma unroll
+        for (uint32_t m = 1; m < 4; m++) {
+            if (m * kMini >= cnt) break;
+            const uint32_t c = min((uint32_t)kMini, cnt - m * kMini);
+            if (pos >= end) return E_CORRUPT;
+            bw = (full && pos == p1 + (m - 1) * stride) ? spec[m - 1] : base[pos];
+            pos++;
+            if (bw > (uint32_t)width || pos >= (1u << 24)) return E_CORRUPT;
+            if (write) mb[b * 4 + m] = pos | (bw << 24);
+            pos += ((c + 7) >> 3) * bw;
+            if (pos > end) return E_CORRUPT;
+        }
+        if (full && pos == p4 && p4 < end) { lo = nlo; hi = nhi; have = true; }
     }
-    if (!w.err && w.pos != w.end) w.err = E_CORRUPT;
-    return w.err;
+    return pos != end ? E_CORRUPT : 0;
 }
 
 // Walk the RLE/bit-packing hybrid id stream (RLEPackingHybridCodec.decodeInts, RLEPackingHybridCodec.java:97-128) and

@@ -265,6 +265,43 @@ def test_corrupted_packs_fail_cleanly():
     assert status[0] == L.ERR_DATA_CORRUPTED
 
 
+def test_lane_walk_agrees_with_window_walk_on_corrupted_packs():
+    """Batches of 16384 packs and more take the lane-per-stream framing walk.  Mutated packs (flips anywhere in the first
+    kilobyte: stream lengths, varints, mini-block width bytes, segment headers) must get the same status and the same
+    bytes from it as from the window walk of a small batch."""
+    r = rng(91)
+    base = []
+    for data_type in ALL_TYPES:
+        base.append(oracle_case(_column(r, data_type, 5000, 300), data_type, O.DICT_COMPRESS))
+        base.append(oracle_case(_column(r, data_type, 5000, 3000), data_type, O.DELTA))
+    seq = (np.cumsum(r.integers(0, 2001, 20000)) + 1500000000000).astype("<i8")  # one width per block: the walk's guess holds
+    base.append(oracle_case(seq, L.LONG, O.DICT_COMPRESS))
+    base.append(oracle_case(seq.astype("<i4"), L.INT, O.DELTA))
+    cases = list(base)
+    for c in base:
+        p = c.pack
+        cases.append(Case(p[:len(p) - 5], c.data_type, c.encode_type, c.n, c.data_size, None, c.name + " truncated"))
+        for k in range(12):
+            q = p.copy()
+            pos = int(r.integers(0, min(len(q), 1024)))
+            q[pos] ^= 1 << int(r.integers(0, 8))
+            cases.append(Case(q, c.data_type, c.encode_type, c.n, c.data_size, None, c.name + " flip%d@%d" % (k, pos)))
+    outs_a, status_a, plan = run_batch(cases)
+    plan.destroy()
+    filler = base[0]
+    big = cases + [filler] * (16384 - len(cases) + 8)
+    outs_b, status_b, plan = run_batch(big)
+    plan.destroy()
+    assert len({int(x) for x in status_a}) > 3  # clean packs and more than one kind of failure
+    for i, c in enumerate(cases):
+        assert status_a[i] == status_b[i], (c.name, status_a[i], status_b[i])
+        if status_a[i] >= 0:
+            assert outs_a[i].tobytes() == outs_b[i].tobytes(), c.name
+    for i, c in enumerate(base):
+        assert status_b[i] == len(c.pack) and outs_b[i].tobytes() == c.expect.tobytes(), c.name
+    assert all(int(x) == len(filler.pack) for x in status_b[len(cases):])
+
+
 def test_bad_arguments():
     d = L.PackDesc(8, 0, 10, 40, 10, L.ENC_DELTA, L.INT, 0)  # misaligned in_off
     with pytest.raises(L.IxrError):
