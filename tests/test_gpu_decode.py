@@ -302,6 +302,26 @@ def test_lane_walk_agrees_with_window_walk_on_corrupted_packs():
     assert all(int(x) == len(filler.pack) for x in status_b[len(cases):])
 
 
+def test_string_packs_of_mixed_dictionary_sizes_in_a_large_launch():
+    """From 1024 string packs on, the index kernel runs in workgroups of 4 waves instead of 16.  Dictionaries from 40 to 30000
+    entries side by side in one such launch."""
+    r = rng(5)
+
+    def uniq(m, n):
+        words = [b"k%07d" % i + bytes(r.integers(97, 123, int(r.integers(0, 9))).astype(np.uint8)) for i in range(m)]
+        rows = [words[i] for i in r.integers(0, m, n)]
+        rows[:m] = words  # every entry is used
+        return rows
+    small = oracle_case(uniq(40, 300), L.STRING, O.DICT_COMPRESS, name="40 entries")
+    edge_in = oracle_case(uniq(12287, 14000), L.STRING, O.DICT_COMPRESS, name="12287 entries")
+    edge_out = oracle_case(uniq(12288, 14000), L.STRING, O.DICT_COMPRESS, name="12288 entries")
+    big = oracle_case(uniq(30000, 40000), L.STRING, O.DICT_COMPRESS, name="30000 entries")
+    cases = []
+    for i in range(1040):
+        cases.append((small, edge_in, small, edge_out, small, big)[i % 6] if i % 40 < 6 else small)
+    check_cases(cases)
+
+
 def test_bad_arguments():
     d = L.PackDesc(8, 0, 10, 40, 10, L.ENC_DELTA, L.INT, 0)  # misaligned in_off
     with pytest.raises(L.IxrError):
