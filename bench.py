@@ -482,8 +482,52 @@ def time_filter(L, np, device, sample, scratch_gib):
     scan = {"ms": round(scan_best * 1e3, 3), "rows_per_s": round(plan.total_rows / scan_best, 1),
             "read_GBps": round(plan.total_out / scan_best / 1e9, 1), "checked_vs_oracle": scan_checked,
             "note": "wall time of ixr_scan_filter_run on the decoded packs (>= one key per pack), incl. uploads, result download, sync"}
+    # the rows those bitmaps pick, compacted on the device (DataPack.foreach(BitMap, setter) in batch form)
+    sel, dst = [], 0
+    for i, d in enumerate(descs):
+        sd = L.SelectDesc(d.out_off, dst, i * L.BITMAP_BYTES, d.data_type, d.obj_count, d.data_size, 0)
+        sel.append(sd)
+        dst += (int(L.lib.ixr_select_bound(sd)) + 255) // 256 * 256
+    d_sel = L.DeviceBuffer(device, dst)
+    sel_best = None
+    for it in range(4):
+        L.lib.ixr_dev_synchronize(device)
+        t = time.perf_counter()
+        cnt, nbad = L.select_run(sel, d_out.ptr, plan.out_bytes, d_bm.ptr, L.BITMAP_BYTES * plan.n, d_sel.ptr, dst, device=device)
+        dt = time.perf_counter() - t
+        if it and (sel_best is None or dt < sel_best):
+            sel_best = dt
+    if nbad:
+        raise SystemExit("select failed on %d packs" % nbad)
+    sel_checked, seen4, hsel = 0, {}, d_sel.download()
+    for i, d in enumerate(descs):
+        if seen4.get(d.data_type, 0) >= 1:
+            continue
+        seen4[d.data_type] = 1
+        want, ids, vals = O.select_pack(dec[d.out_off:d.out_off + d.data_size], d.data_type, d.obj_count, host3[i])
+        n, base = d.obj_count, sel[i].dst_off
+        got_ids = hsel[base:base + 4 * n].view("<i4")[:want]
+        ok = int(cnt[i]) == want and (got_ids == ids).all()
+        if ok and d.data_type == 5:
+            ao = hsel[base + 4 * n:base + 8 * n].view("<i4")[:want]
+            al = hsel[base + 8 * n:base + 12 * n].view("<i4")[:want]
+            body = hsel[base + 12 * n:base + int(L.lib.ixr_select_bound(sel[i]))].tobytes()
+            ok = [body[ao[k]:ao[k] + al[k]] for k in range(want)] == vals
+        elif ok:
+            w = vals.dtype.itemsize
+            vo = base + ((4 * n + 7) & ~7)
+            ok = hsel[vo:vo + w * want].tobytes() == vals.tobytes()
+        if not ok:
+            raise SystemExit("select differs from the oracle on pack %d" % i)
+        sel_checked += 1
+    picked = int(cnt.astype(np.int64).sum())
+    select = {"ms": round(sel_best * 1e3, 3), "rows_per_s": round(plan.total_rows / sel_best, 1), "picked_rows": picked,
+              "picked_fraction": round(picked / plan.total_rows, 4), "checked_vs_oracle": sel_checked,
+              "note": "wall time of ixr_select_run on the decoded packs and the scan filter's bitmaps, incl. uploads, count download, sync"}
+    d_sel.free()
     d_out.free()
     out = {"rows_per_s": round(plan.total_rows / best, 1), "packs": plan.n, "ms": round(best * 1e3, 3), "results": kinds, "like": like, "scan": scan,
+           "select": select,
            "checked_vs_oracle": checked, "cpu_oracle_rows_per_s_1_thread": round(cpu_rows / cpu_s, 1),
            "equivalent_decoded_GBps": round(plan.total_out / best / 1e9, 1),
            "note": "wall time of ixr_plan_run_filter (parse + dictionaries + key search + row pass, incl. uploads, result download, sync); rows are never decoded"}

@@ -2257,39 +2257,28 @@ __global__ __launch_bounds__(256) void k_scan_filter(const ScanFilterDesc* __res
 // ---------------------------------------------------------------------------------------------------------------
 // k_select: the rows of a decoded pack that a bitmap picks, in row order (DataPack.foreach(BitMap position, XxxSetter),
 // DataPack.java:273-306, 324-357, 375-408, 426-459, 708-762: every set bit below objCount; BitMap.ALL is every row).
-// One workgroup of 1024 threads per descriptor; a tile of 1024 rows per round, positions by a workgroup scan.
+// One workgroup of 16 waves per descriptor; a wave owns 64 bitmap words (4096 rows), one word per lane.  Popcounts give
+// every word's first output position (wave scan, one workgroup exchange of the 16 wave totals); then the wave goes
+// through its words, lane l looking at bit l: the picked rows of a word land next to each other, so loads and stores
+// stay contiguous.  Strings add the same two steps for byte positions (sum of the picked lengths).
 //   numbers   int32 rowId[n] | value[n] (8-byte values start at a multiple of 8)
 //   strings   int32 rowId[n] | int32 arrayOffset[n] | int32 arrayLength[n] | the picked rows' bytes one after the other
 // counts[d] = number of picked rows, or a negative error.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename U>
-__device__ __forceinline__ U wg1024_excl_scan(U v, U* s_w, U* total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const U incl = wave_incl_scan<U>(v);
-    if (lane == 63) s_w[wave] = incl;
-    __syncthreads();
-    if (wave == 0) {
-        const U x = lane < 16 ? s_w[lane] : (U)0;
-        const U xi = wave_incl_scan<U>(x);
-        if (lane < 16) s_w[lane] = xi - x;
-        if (lane == 15) s_w[16] = xi;
-    }
-    __syncthreads();
-    const U r = s_w[wave] + incl - v;
-    *total = s_w[16];
-    __syncthreads();
-    return r;
-}
 __global__ __launch_bounds__(1024) void k_select(const SelectDesc* __restrict__ descs, const uint8_t* __restrict__ decoded,
                                                  const uint8_t* __restrict__ bitmaps, uint8_t* __restrict__ out, int32_t* __restrict__ counts) {
-    __shared__ uint32_t s_w[17];
-    __shared__ unsigned long long s_wb[17];  // byte positions: 1024 rows of up to 2^31 bytes each
+    // readlane hands back a signed int: widen through uint32_t
+    auto lane64 = [](unsigned long long v, int j) {
+        return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(v >> 32), j) << 32) |
+               (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((uint32_t)v, j);
+    };
+    __shared__ uint32_t s_cnt[16];
+    __shared__ unsigned long long s_bytes[16];
     __shared__ int s_bad;
     const SelectDesc D = descs[blockIdx.x];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t n = (uint32_t)D.obj_count;
     const uint8_t* src = decoded + D.src_off;
-    const unsigned long long* bm = (const unsigned long long*)(bitmaps + D.bitmap_off);
     uint8_t* dst = out + D.dst_off;
     int32_t* row_id = (int32_t*)dst;
     const int dt = D.data_type;
@@ -2299,50 +2288,126 @@ __global__ __launch_bounds__(1024) void k_select(const SelectDesc* __restrict__ 
         return;
     }
     if (tid == 0) s_bad = 0;
-    __syncthreads();
+    // this lane's word: rows [64 * wi, 64 * wi + 64), bits at and above objCount dropped
+    const uint32_t wi = (uint32_t)wave * 64u + (uint32_t)lane;
+    unsigned long long word = 0;
+    if (wi * 64u < n) {
+        word = D.all ? ~0ull : ((const unsigned long long*)(bitmaps + D.bitmap_off))[wi];
+        if (n - wi * 64u < 64u) word &= (1ull << (n - wi * 64u)) - 1ull;
+    }
+    const uint32_t c = (uint32_t)__popcll(word);
+    const uint32_t c_incl = wave_incl_scan<uint32_t>(c);
+    if (lane == 63) s_cnt[wave] = c_incl;
+    const unsigned long long below = (1ull << lane) - 1ull;
+
     const int32_t* off = (const int32_t*)src;
     const uint8_t* body = src + 4ull * (n + 1);
     const int64_t body_cap = (int64_t)D.data_size - 4ll * (n + 1);
+    bool bad = false;
+    if (dt == 5) {  // strings: the bytes this wave picks, for the waves after it
+        unsigned long long mine = 0;
+        for (int j = 0; j < 64; j++) {
+            const unsigned long long wj = lane64(word, j);
+            if (!((wj >> lane) & 1ull)) continue;
+            const uint32_t r = ((uint32_t)wave * 64u + (uint32_t)j) * 64u + (uint32_t)lane;
+            const int32_t a = off[r], b = off[r + 1];
+            if (a < 0 || b < a || (int64_t)b > body_cap) bad = true;
+            else mine += (uint32_t)(b - a);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+        if (lane == 0) s_bytes[wave] = mine;
+    }
+    __syncthreads();
+    uint32_t count_base = 0, total = 0;
+    unsigned long long byte_base = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t v = s_cnt[k];
+        count_base += k < wave ? v : 0u;
+        total += v;
+        if (dt == 5) byte_base += k < wave ? s_bytes[k] : 0ull;
+    }
+    const uint32_t c_excl = count_base + c_incl - c;  // first output position of this lane's word
+
     int32_t* aoff = row_id + n;
     int32_t* alen = aoff + n;
     uint8_t* bytes = dst + 12ull * n;
     uint8_t* vals = dst + ((4ull * n + 7) & ~7ull);
-    uint32_t count = 0;
-    unsigned long long byte_pos = 0;
-    for (uint32_t base = 0; base < n; base += 1024) {
-        const uint32_t r = base + tid;
-        bool pick = r < n && (D.all || ((bm[r >> 6] >> (r & 63)) & 1ull));
-        int32_t a = 0, len = 0;
-        if (pick && dt == 5) {
-            a = off[r];
-            const int32_t b = off[r + 1];
-            if (a < 0 || b < a || (int64_t)b > body_cap) { s_bad = 1; pick = false; }
-            len = b - a;
-        }
-        uint32_t tot;
-        const uint32_t pos = count + wg1024_excl_scan<uint32_t>(pick ? 1u : 0u, s_w, &tot);
-        count += tot;
-        if (dt == 5) {
-            unsigned long long btot;
-            const unsigned long long bp = byte_pos + wg1024_excl_scan<unsigned long long>(pick ? (unsigned long long)len : 0ull, s_wb, &btot);
-            byte_pos += btot;
-            // rows whose offsets step backwards in between can overlap: more bytes than the pack's body holds do not fit
-            if (pick && bp + (unsigned long long)len > (unsigned long long)body_cap) { s_bad = 1; pick = false; }
+    for (int j = 0; j < 64; j++) {
+        const unsigned long long wj = lane64(word, j);
+        if (wj == 0) continue;
+        const bool pick = (wj >> lane) & 1ull;
+        const uint32_t r = ((uint32_t)wave * 64u + (uint32_t)j) * 64u + (uint32_t)lane;
+        const uint32_t pos = (uint32_t)__builtin_amdgcn_readlane(c_excl, j) + (uint32_t)__popcll(wj & below);
+        if (dt != 5) {
             if (pick) {
                 row_id[pos] = (int32_t)r;
-                aoff[pos] = (int32_t)bp;
-                alen[pos] = len;
-                const uint8_t* sp = body + a;
-                for (int32_t k = 0; k < len; k++) bytes[bp + k] = sp[k];
+                if (w == 4) ((uint32_t*)vals)[pos] = ((const uint32_t*)src)[r];
+                else ((uint64_t*)vals)[pos] = ((const uint64_t*)src)[r];
             }
-        } else if (pick) {
+            continue;
+        }
+        int32_t a = 0;
+        uint32_t len = 0;
+        bool ok = pick;
+        if (pick) {
+            a = off[r];
+            const int32_t b = off[r + 1];
+            if (a < 0 || b < a || (int64_t)b > body_cap) ok = false;  // reported by the first pass
+            else len = (uint32_t)(b - a);
+        }
+        const unsigned long long l_incl = wave_incl_scan<unsigned long long>((unsigned long long)len);
+        const unsigned long long bp = byte_base + l_incl - len;
+        byte_base += lane64(l_incl, 63);  // the next word's bytes follow this word's
+        // rows whose offsets step backwards in between can overlap: more bytes than the pack's body holds do not fit
+        if (ok && bp + len > (unsigned long long)body_cap) { bad = true; ok = false; }
+        if (ok) {
             row_id[pos] = (int32_t)r;
-            if (w == 4) ((uint32_t*)vals)[pos] = ((const uint32_t*)src)[r];
-            else ((uint64_t*)vals)[pos] = ((const uint64_t*)src)[r];
+            aoff[pos] = (int32_t)bp;
+            alen[pos] = (int32_t)len;
+            // Neither side is aligned; the memory system takes unaligned accesses.  No byte loops: a piece that ends at the
+            // row's last byte covers the tail and may overlap the piece before it (same bytes, same lane, program order).
+            const uint8_t* sp = body + a;
+            uint8_t* dp = bytes + bp;
+            auto piece = [&](uint32_t at, auto tag) {
+                decltype(tag) v;
+                __builtin_memcpy(&v, sp + at, sizeof(v));
+                __builtin_memcpy(dp + at, &v, sizeof(v));
+            };
+            if (len >= 16) {
+                uint32_t k = 0;
+                for (; k + 64 <= len; k += 64) {
+                    uint4 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) __builtin_memcpy(&v[q], sp + k + 16 * q, 16);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) __builtin_memcpy(dp + k + 16 * q, &v[q], 16);
+                }
+                const uint32_t m = (len - k) >> 4;  // 0..3 whole pieces left, then the tail piece
+                uint4 v[4];
+#pragma unroll
+                for (uint32_t q = 0; q < 3; q++)
+                    if (q < m) __builtin_memcpy(&v[q], sp + k + 16 * q, 16);
+                __builtin_memcpy(&v[3], sp + len - 16, 16);
+#pragma unroll
+                for (uint32_t q = 0; q < 3; q++)
+                    if (q < m) __builtin_memcpy(dp + k + 16 * q, &v[q], 16);
+                __builtin_memcpy(dp + len - 16, &v[3], 16);
+            } else if (len >= 8) {
+                piece(0, uint2{}); piece(len - 8, uint2{});
+            } else if (len >= 4) {
+                piece(0, uint32_t{}); piece(len - 4, uint32_t{});
+            } else if (len >= 2) {
+                piece(0, uint16_t{}); piece(len - 2, uint16_t{});
+            } else if (len == 1) {
+                dp[0] = sp[0];
+            }
         }
     }
+    if (bad) s_bad = 1;
     __syncthreads();
-    if (tid == 0) counts[blockIdx.x] = s_bad ? E_CORRUPT : (int32_t)count;
+    if (tid == 0) counts[blockIdx.x] = s_bad ? E_CORRUPT : (int32_t)total;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
