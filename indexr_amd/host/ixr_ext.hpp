@@ -5,6 +5,9 @@
 //                       when dpn.isDictEncoded(), ExtIndex_SimpleBits otherwise
 //   PackEncodeBatch     DataPackCreator_VLT.from(...) + DataPack.compress for many packs at once
 //                       (DataPackCreator_VLT.java:21-213, DataPack.java:150-163)
+//   PackForeachBatch    DataPack.foreach(BitMap position, XxxSetter) for many packs at once (DataPack.java:273-306,
+//                       324-357, 375-408, 426-459, 708-762): packs are decoded and the picked rows compacted on the device,
+//                       only those come back
 #ifndef IXR_EXT_HPP
 #define IXR_EXT_HPP
 #include "ixr_host.hpp"
@@ -240,6 +243,116 @@ private:
     struct Item { uint8_t dataType; bool isIndexed; DataPackNode dpn; ByteSlice data; ByteSlice cmp; };
     int device_;
     std::vector<Item> items_;
+};
+
+// Decodes many packs and hands out the rows a BitMap picks in each, as DataPack.foreach(BitMap position, XxxSetter) does
+// pack by pack: after run(), foreachInt / Long / Float / Double / Bytes(i, setter) make the same setter calls, in the same
+// order, and return the same count.  BitMap::ALL is the reference's BitMap.ALL (every row), NONE picks nothing.
+class PackForeachBatch {
+public:
+    explicit PackForeachBatch(int device = 0) : device_(device) {}
+    int add(uint8_t dataType, const DataPackNode& dpn, const ByteSlice& cmpData, const BitMap& position) {
+        if ((size_t)dpn.packSize != cmpData.size()) throw std::runtime_error("cmpData size != dpn.packSize");
+        if (position.kind == BitMap::SOME && position.words.size() != 1024) throw std::runtime_error("a BitMap has 1024 words");
+        items_.push_back({dataType, dpn, cmpData, position, 0, 0});
+        return (int)items_.size() - 1;
+    }
+    int size() const { return (int)items_.size(); }
+    int count(int i) const { return items_.at((size_t)i).count; }
+
+    void run() {
+        const int n = (int)items_.size();
+        if (n == 0) return;
+        struct Dev { int device; std::vector<void*> dev; ixr_plan* plan = nullptr;
+                     ~Dev() { if (plan) ixr_plan_destroy(plan); for (void* p : dev) ixr_dev_free(device, p); }
+                     void* alloc(uint64_t b) { void* p = ixr_dev_alloc(device, std::max<uint64_t>(b, 16)); if (!p) throw ixr_failure("ixr_dev_alloc", IXR_ERR_OUT_OF_MEMORY); dev.push_back(p); return p; } } m{device_, {}};
+        std::vector<ixr_pack_desc> descs((size_t)n);
+        std::vector<ixr_select_desc> sel((size_t)n);
+        uint64_t in_bytes = 0, out_bytes = 0, dst = 0;
+        for (int k = 0; k < n; k++) {
+            Item& it = items_[(size_t)k];
+            descs[(size_t)k] = it.dpn.desc(it.dataType, in_bytes, out_bytes);
+            in_bytes += ((uint64_t)it.dpn.packSize + 15) & ~15ull;
+            out_bytes += ((uint64_t)it.dpn.dataSize + 15) & ~15ull;
+            ixr_select_desc& d = sel[(size_t)k];
+            d.src_off = descs[(size_t)k].out_off; d.dst_off = dst; d.bitmap_off = (uint64_t)k * IXR_BITMAP_BYTES;
+            d.data_type = it.dataType; d.obj_count = it.dpn.objCount; d.data_size = it.dpn.dataSize;
+            d.all = it.position.kind == BitMap::ALL ? 1 : 0;
+            it.out_off = dst;
+            dst += (ixr_select_bound(&d) + 255) & ~255ull;
+        }
+        m.plan = ixr_plan_create(device_, descs.data(), n, 0);
+        if (!m.plan) throw ixr_failure("ixr_plan_create", -1);
+        const uint64_t in_need = ixr_plan_in_bytes(m.plan), out_need = std::max<uint64_t>(ixr_plan_out_bytes(m.plan), 16);
+        std::vector<uint8_t> h_in((size_t)in_need, 0), h_bm((size_t)n * IXR_BITMAP_BYTES, 0);
+        for (int k = 0; k < n; k++) {
+            const Item& it = items_[(size_t)k];
+            std::memcpy(h_in.data() + descs[(size_t)k].in_off, it.cmp.address(), it.cmp.size());
+            if (it.position.kind == BitMap::SOME) std::memcpy(h_bm.data() + (size_t)k * IXR_BITMAP_BYTES, it.position.words.data(), IXR_BITMAP_BYTES);
+        }
+        void *d_in = m.alloc(in_need), *d_out = m.alloc(out_need), *d_bm = m.alloc(h_bm.size()), *d_sel = m.alloc(dst);
+        int32_t rc = ixr_memcpy_h2d(device_, d_in, h_in.data(), in_need);
+        if (!rc) rc = ixr_memcpy_h2d(device_, d_bm, h_bm.data(), h_bm.size());
+        if (rc) throw ixr_failure("ixr_memcpy_h2d", rc);
+        rc = ixr_plan_run(m.plan, d_in, in_need, d_out, out_need, nullptr);
+        if (rc) throw ixr_failure("ixr_plan_run", rc);
+        std::vector<int32_t> status((size_t)n), counts((size_t)n);
+        if (ixr_plan_status(m.plan, status.data(), nullptr) != 0) throw std::runtime_error("pack(s) failed to decode (consumed != packSize)");
+        rc = ixr_select_run(device_, sel.data(), n, d_out, out_need, d_bm, h_bm.size(), d_sel, std::max<uint64_t>(dst, 16), counts.data(), nullptr);
+        if (rc < 0) throw ixr_failure("ixr_select_run", rc);
+        if (rc > 0) throw std::runtime_error(std::to_string(rc) + " pack(s) with string offsets outside the pack");
+        picked_.assign((size_t)dst, 0);
+        rc = ixr_memcpy_d2h(device_, picked_.data(), d_sel, dst);
+        if (rc) throw ixr_failure("ixr_memcpy_d2h", rc);
+        for (int k = 0; k < n; k++) items_[(size_t)k].count = counts[(size_t)k];
+    }
+
+    template <typename F> int foreachInt(int i, F setter) const { return numbers<int32_t>(i, ColumnType::INT, setter); }
+    template <typename F> int foreachLong(int i, F setter) const { return numbers<int64_t>(i, ColumnType::LONG, setter); }
+    template <typename F> int foreachFloat(int i, F setter) const { return numbers<float>(i, ColumnType::FLOAT, setter); }
+    template <typename F> int foreachDouble(int i, F setter) const { return numbers<double>(i, ColumnType::DOUBLE, setter); }
+    // setter(index, BytePiece): the piece points into this batch's memory
+    template <typename F> int foreachBytes(int i, F setter) const {
+        const Item& it = item(i, ColumnType::STRING);
+        const size_t n = (size_t)it.dpn.objCount;
+        const uint8_t* base = picked_.data() + it.out_off;
+        DataPack::BytePiece bp;
+        for (int k = 0; k < it.count; k++) {
+            int32_t id, off, len;
+            std::memcpy(&id, base + 4 * (size_t)k, 4);
+            std::memcpy(&off, base + 4 * n + 4 * (size_t)k, 4);
+            std::memcpy(&len, base + 8 * n + 4 * (size_t)k, 4);
+            bp.addr = base + 12 * n + (size_t)off;
+            bp.len = len;
+            setter((int)id, bp);
+        }
+        return it.count;
+    }
+
+private:
+    struct Item { uint8_t dataType; DataPackNode dpn; ByteSlice cmp; BitMap position; uint64_t out_off; int count; };
+    const Item& item(int i, uint8_t type) const {
+        const Item& it = items_.at((size_t)i);
+        if (it.dataType != type) throw std::runtime_error("pack " + std::to_string(i) + " holds another data type");
+        return it;
+    }
+    template <typename T, typename F> int numbers(int i, uint8_t type, F setter) const {
+        const Item& it = item(i, type);
+        const size_t n = (size_t)it.dpn.objCount;
+        const uint8_t* base = picked_.data() + it.out_off;
+        const uint8_t* vals = base + ((4 * n + 7) & ~(size_t)7);
+        for (int k = 0; k < it.count; k++) {
+            int32_t id;
+            T v;
+            std::memcpy(&id, base + 4 * (size_t)k, 4);
+            std::memcpy(&v, vals + sizeof(T) * (size_t)k, sizeof(T));
+            setter((int)id, v);
+        }
+        return it.count;
+    }
+    int device_;
+    std::vector<Item> items_;
+    std::vector<uint8_t> picked_;
 };
 
 }  // namespace indexr

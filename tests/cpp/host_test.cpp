@@ -428,6 +428,70 @@ static void test_encode_batch_gpu(VersionAdapter& va) {
     CHECK(delta == 1);
 }
 
+// DataPack.foreach(BitMap position, setter) for a batch of packs on the device: the same setter calls as row by row on the host
+static void test_foreach_batch_gpu(VersionAdapter& va) {
+    std::vector<int32_t> iv(50000);
+    std::vector<int64_t> lv(65536);
+    std::vector<float> fv(777);
+    std::vector<double> dv(30000);
+    std::vector<std::string> sv;
+    for (size_t i = 0; i < iv.size(); i++) iv[i] = (int32_t)((i * 2654435761u) % 1000) - 500;
+    for (size_t i = 0; i < lv.size(); i++) lv[i] = 1500000000000LL + (int64_t)i * 977;
+    for (size_t i = 0; i < fv.size(); i++) fv[i] = (float)((i * 40503u) % 100) / 10.0f;
+    for (size_t i = 0; i < dv.size(); i++) dv[i] = (double)((i * 69069u) % 50000) / 10.0;
+    for (int i = 0; i < 25000; i++) sv.push_back(i % 9 == 0 ? std::string() : "www.host" + std::to_string((i * 7) % 300) + ".com/p/" + std::to_string((i * 13) % 41));
+    struct P { uint8_t dt; DataPack pack; };
+    std::vector<P> ps;
+    ps.push_back({ColumnType::INT, DataPack::fromInts(iv.data(), (int)iv.size())});
+    ps.push_back({ColumnType::LONG, DataPack::fromLongs(lv.data(), (int)lv.size())});
+    ps.push_back({ColumnType::FLOAT, DataPack::fromFloats(fv.data(), (int)fv.size())});
+    ps.push_back({ColumnType::DOUBLE, DataPack::fromDoubles(dv.data(), (int)dv.size())});
+    ps.push_back({ColumnType::STRING, DataPack::fromStrings(sv)});
+    for (auto& p : ps) p.pack.compress(va, VERSION, p.dt, true);
+    auto bitmap = [](int rows, int kind) {
+        BitMap b;
+        b.rowCount = rows;
+        if (kind == 0) { b.kind = BitMap::ALL; return b; }
+        if (kind == 1) { b.kind = BitMap::NONE; return b; }
+        b.kind = BitMap::SOME;
+        b.words.assign(1024, 0);
+        for (int r = 0; r < 65536; r++)  // bits at and above objCount stay set: the loop stops there
+            if (kind == 2 ? (r * 2654435761u) % 7 < 3 : r % 1000 == 999) b.words[(size_t)r >> 6] |= 1ull << (r & 63);
+        return b;
+    };
+    PackForeachBatch batch(0);
+    std::vector<std::pair<int, int>> what;  // pack, bitmap kind
+    for (int p = 0; p < (int)ps.size(); p++)
+        for (int kind = 0; kind < 4; kind++) {
+            batch.add(ps[(size_t)p].dt, ps[(size_t)p].pack.dpn(), ps[(size_t)p].pack.cmpData(), bitmap(ps[(size_t)p].pack.dpn().objCount, kind));
+            what.push_back({p, kind});
+        }
+    batch.run();
+    for (int i = 0; i < batch.size(); i++) {
+        const P& p = ps[(size_t)what[(size_t)i].first];
+        const BitMap pos = bitmap(p.pack.dpn().objCount, what[(size_t)i].second);
+        std::vector<int> want;
+        for (int r = 0; r < p.pack.dpn().objCount; r++)
+            if (pos.get(r)) want.push_back(r);
+        size_t k = 0;
+        bool same = true;
+        int got = 0;
+        auto row = [&](int id) { const bool ok = k < want.size() && want[k] == id; k++; return ok; };
+        switch (p.dt) {
+            case ColumnType::INT: got = batch.foreachInt(i, [&](int id, int32_t v) { same = same && row(id) && v == iv[(size_t)id]; }); break;
+            case ColumnType::LONG: got = batch.foreachLong(i, [&](int id, int64_t v) { same = same && row(id) && v == lv[(size_t)id]; }); break;
+            case ColumnType::FLOAT: got = batch.foreachFloat(i, [&](int id, float v) { same = same && row(id) && v == fv[(size_t)id]; }); break;
+            case ColumnType::DOUBLE: got = batch.foreachDouble(i, [&](int id, double v) { same = same && row(id) && v == dv[(size_t)id]; }); break;
+            default:
+                got = batch.foreachBytes(i, [&](int id, const DataPack::BytePiece& b) {
+                    same = same && row(id) && std::string((const char*)b.addr, (size_t)b.len) == sv[(size_t)id];
+                });
+        }
+        CHECK(same);
+        CHECK(got == (int)want.size() && k == want.size() && batch.count(i) == got);
+    }
+    CHECK_THROWS(batch.foreachInt(4, [](int, int32_t) {}), "another data type");
+}
 int main(int argc, char** argv) {
     if (argc < 3) { std::fprintf(stderr, "usage: host_test --cpu|--gpu <tmpdir>\n"); return 2; }
     const std::string mode = argv[1], dir = argv[2];
@@ -448,6 +512,7 @@ int main(int argc, char** argv) {
             test_segment_scan_gpu(va, dir);
             test_ext_index_gpu(va);
             test_encode_batch_gpu(va);
+            test_foreach_batch_gpu(va);
         } else {
             return 2;
         }
