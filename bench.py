@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU time of each cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-exclusive", action="store_true", help="skip the extra pass (outside the timed region) that times every kernel alone on the device")
+    ap.add_argument("--dict-structs", action="store_true", help="also time the uncompressed DictStruct of every dictionary pack of the first chunk (PackCompressor_VLT.getDictStruct in batch form), checked against the oracle")
     ap.add_argument("--handback", action="store_true", help="also time the engine hand-back (decoded packs -> Spark column vector contents) on the first chunk, checked against the oracle")
     ap.add_argument("--filter", action="store_true", help="also time predicate evaluation on dictionary ids (rows -> bitmap without decoding) on the first chunk, checked against the oracle")
     ap.add_argument("--encode", action="store_true", help="also time the device encoder on the numeric packs of the first chunk (decode, then re-encode); the bytes are compared with the packs the decode started from")
@@ -230,6 +231,10 @@ def main():
     if args.with_copies and rank == 0:
         with_copies = time_with_copies(L, np, device, sample_for_cpu, args.scratch_gib)
 
+    dict_structs = None
+    if args.dict_structs and rank == 0:
+        dict_structs = time_dict_structs(L, np, device, sample_for_cpu, args.scratch_gib)
+
     handback = None
     if args.handback and rank == 0:
         handback = time_handback(L, np, device, sample_for_cpu, args.scratch_gib)
@@ -272,6 +277,8 @@ def main():
         }
         if with_copies:
             out["with_copies"] = with_copies
+        if dict_structs:
+            out["dict_structs"] = dict_structs
         if handback:
             out["handback"] = handback
         if filt:
@@ -379,6 +386,58 @@ def time_with_copies(L, np, device, sample, scratch_gib):
            "note": "synchronous H2D -> decode -> D2H from/to pinned host memory, no overlap"}
     plan.destroy(); d_in.free(); d_out.free()
     L.lib.ixr_host_free_pinned(h_in); L.lib.ixr_host_free_pinned(h_out)
+    return res
+
+
+def time_dict_structs(L, np, device, sample, scratch_gib):
+    """PackCompressor_VLT.getDictStruct (:172-186) for every dictionary pack of the first chunk in one call: the uncompressed
+    DictStruct (entryCount | entries | 4n | ids as int32) of each pack, left on the device; a few are compared with the CPU
+    oracle, which is also timed on one thread."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    descs, arena = sample
+    plan = L.Plan(device, descs, int(scratch_gib * (1 << 30)))
+    in_bytes = len(arena)
+    d_in = L.DeviceBuffer(device, in_bytes)
+    d_in.upload(arena)
+    ds_off, off = [], 0
+    for d in descs:
+        ds_off.append(off)
+        off += (8 + d.data_size + 4 * d.obj_count + 15) & ~15  # upper bound: dictionary <= dataSize
+    d_out = L.DeviceBuffer(device, off + 16)
+    best = None
+    for it in range(4):
+        L.lib.ixr_dev_synchronize(device)
+        t = time.perf_counter()
+        plan.run_dict_structs(d_in.ptr, in_bytes, d_out.ptr, off + 16, ds_off)
+        status, nbad = plan.status()
+        dt = time.perf_counter() - t
+        if it and (best is None or dt < best):
+            best = dt
+    if nbad:
+        raise SystemExit("DictStruct run failed on %d packs" % nbad)
+    host = d_out.download()
+    checked, seen, cpu_s, cpu_bytes, total = 0, {}, 0.0, 0, 0
+    for i, d in enumerate(descs):
+        if d.encode_type != 6:
+            continue
+        size = int(arena[d.in_off:d.in_off + 4].view("<i4")[0])  # the pack's first word: dictStructSize
+        total += size
+        if seen.get(d.data_type, 0) >= 2:
+            continue
+        seen[d.data_type] = seen.get(d.data_type, 0) + 1
+        t = time.perf_counter()
+        want, consumed = O.get_dict_struct(arena[d.in_off:d.in_off + d.pack_size], d.data_type, d.obj_count)
+        cpu_s += time.perf_counter() - t
+        cpu_bytes += len(want)
+        if consumed != d.pack_size or host[ds_off[i]:ds_off[i] + len(want)].tobytes() != want.tobytes():
+            raise SystemExit("DictStruct differs from the oracle on pack %d" % i)
+        checked += 1
+    res = {"GBps_out": round(total / best / 1e9, 1), "rows_per_s": round(plan.total_rows / best, 1), "packs": plan.n, "ms": round(best * 1e3, 3),
+           "dict_struct_GB": round(total / 1e9, 3), "checked_vs_oracle": checked,
+           "cpu_oracle_GBps_1_thread": round(cpu_bytes / cpu_s / 1e9, 3),
+           "note": "wall time of ixr_plan_run_dict_structs + ixr_plan_status (descriptor upload, parse, dictionaries, id expansion, sync)"}
+    plan.destroy(); d_in.free(); d_out.free()
     return res
 
 
