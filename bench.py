@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-exclusive", action="store_true", help="skip the extra pass (outside the timed region) that times every kernel alone on the device")
     ap.add_argument("--dict-structs", action="store_true", help="also time the uncompressed DictStruct of every dictionary pack of the first chunk (PackCompressor_VLT.getDictStruct in batch form), checked against the oracle")
+    ap.add_argument("--raw-yardstick", action="store_true", help="also time the same packs stored uncompressed (dpn.compress() == false: data = cmpData, DataPack.java:180-182) through the same plan machinery: what a decode that cost nothing would reach")
     ap.add_argument("--handback", action="store_true", help="also time the engine hand-back (decoded packs -> Spark column vector contents) on the first chunk, checked against the oracle")
     ap.add_argument("--filter", action="store_true", help="also time predicate evaluation on dictionary ids (rows -> bitmap without decoding) on the first chunk, checked against the oracle")
     ap.add_argument("--encode", action="store_true", help="also time the device encoder on the numeric packs of the first chunk (decode, then re-encode); the bytes are compared with the packs the decode started from")
@@ -235,6 +236,10 @@ def main():
     if args.dict_structs and rank == 0:
         dict_structs = time_dict_structs(L, np, device, sample_for_cpu, args.scratch_gib)
 
+    raw = None
+    if args.raw_yardstick and rank == 0:
+        raw = time_raw_yardstick(L, np, device, sample_for_cpu, args.scratch_gib)
+
     handback = None
     if args.handback and rank == 0:
         handback = time_handback(L, np, device, sample_for_cpu, args.scratch_gib)
@@ -279,6 +284,8 @@ def main():
             out["with_copies"] = with_copies
         if dict_structs:
             out["dict_structs"] = dict_structs
+        if raw:
+            out["raw_yardstick"] = raw
         if handback:
             out["handback"] = handback
         if filt:
@@ -438,6 +445,45 @@ def time_dict_structs(L, np, device, sample, scratch_gib):
            "cpu_oracle_GBps_1_thread": round(cpu_bytes / cpu_s / 1e9, 3),
            "note": "wall time of ixr_plan_run_dict_structs + ixr_plan_status (descriptor upload, parse, dictionaries, id expansion, sync)"}
     plan.destroy(); d_in.free(); d_out.free()
+    return res
+
+
+def time_raw_yardstick(L, np, device, sample, scratch_gib):
+    """The first chunk's packs as uncompressed packs (DataPack.decompress with dpn.compress() == false, DataPack.java:180-182):
+    the decoded arena of a decode is the input, every pack is copied to a second arena by the plan's raw-pack kernel."""
+    descs, arena = sample
+    plan = L.Plan(device, descs, int(scratch_gib * (1 << 30)))
+    in_bytes, out_bytes = len(arena), plan.out_bytes + 16
+    d_in, d_dec = L.DeviceBuffer(device, in_bytes), L.DeviceBuffer(device, out_bytes + L.IN_SLACK)
+    d_in.upload(arena)
+    plan.run(d_in.ptr, in_bytes, d_dec.ptr, out_bytes)
+    _, bad = plan.status()
+    if bad:
+        raise SystemExit("decode failed on %d packs" % bad)
+    total_out = plan.total_out
+    plan.destroy(); d_in.free()
+    raw_descs = [L.PackDesc(d.out_off, d.out_off, d.data_size, d.data_size, d.obj_count, L.ENC_RAW, d.data_type, 0) for d in descs]
+    rplan = L.Plan(device, raw_descs, int(scratch_gib * (1 << 30)))
+    d_copy = L.DeviceBuffer(device, out_bytes)
+    best = None
+    for it in range(5):
+        L.lib.ixr_dev_synchronize(device)
+        t = time.perf_counter()
+        rplan.run(d_dec.ptr, out_bytes + L.IN_SLACK, d_copy.ptr, out_bytes)
+        _, bad = rplan.status()
+        dt = time.perf_counter() - t
+        if it and (best is None or dt < best):
+            best = dt
+    if bad:
+        raise SystemExit("raw copy failed on %d packs" % bad)
+    a, b = d_dec.download(), d_copy.download()
+    for d in descs[:: max(1, len(descs) // 64)]:
+        if a[d.out_off:d.out_off + d.data_size].tobytes() != b[d.out_off:d.out_off + d.data_size].tobytes():
+            raise SystemExit("raw copy differs")
+    res = {"GBps_decoded": round(total_out / best / 1e9, 1), "GBps_read_plus_written": round(2 * total_out / best / 1e9, 1), "packs": rplan.n,
+           "ms": round(best * 1e3, 3), "hbm_fraction": round(2 * total_out / best / 1e9 / HBM_PEAK_GBS, 3),
+           "note": "wall time of ixr_plan_run + ixr_plan_status over the same packs stored uncompressed (parse + 16-byte copies)"}
+    rplan.destroy(); d_dec.free(); d_copy.free()
     return res
 
 
