@@ -121,6 +121,7 @@ def main():
     d_in.upload(np.zeros(L.IN_SLACK, dtype=np.uint8), in_off)
     h2d_s = time.time() - t1
     host_chunks = None
+    table.chunks = None  # the compressed table now lives in HBM; the CPU legs keep the first chunk (table.sample)
     plan = L.Plan(device, all_descs, int(args.scratch_gib * (1 << 30)))
     log("H2D %.2f GB in %.2f s (pageable); plan: scratch %.2f GB" % (in_bytes / 1e9, h2d_s, plan.scratch_bytes / 1e9))
 
