@@ -365,7 +365,7 @@ __device__ __forceinline__ void pack_header(const DevPack& P, const uint8_t* bas
                 m.dict_struct_size = rd32(0);
                 uint32_t ec = rd32(4);
                 uint32_t comp = psz > 8 ? base[8] : 0;
-                if (psz < 9 || ec == 0 || ec > n) { if (!err) err = E_CORRUPT; ec = 1; }
+                if (psz < 9 || ec == 0 || ec > n || (int32_t)m.dict_struct_size < 8) { if (!err) err = E_CORRUPT; ec = 1; }
                 m.entry_count = ec;
                 m.id_bw = bit_width32(ec - 1);
                 uint64_t ids_off;
@@ -1577,6 +1577,12 @@ __global__ __launch_bounds__(kWaves * 64) void k_str_index(const DevPack* __rest
     const uint32_t body_cap = (uint32_t)P.data_size - 4u * (n + 1);
     const uint8_t* base = in + P.in_off;
     const uint32_t* __restrict__ doff = (const uint32_t*)(scratch + P.s_dict);
+    // The reference decodes the DictStruct into a buffer of the dictStructSize the pack announces and fails when it does not
+    // fit (DictCompressCodec.decode, DictCompressCodec.java:71-85; a larger buffer is accepted).  entryCount | offsets | bytes | 4n | ids
+    if (M.dict_struct_size && 4ull + 4ull * (ec + 1) + doff[ec] + 4ull + 4ull * n > (uint64_t)M.dict_struct_size) {
+        if (tid == 0) M.status = E_OVERFLOW;
+        return;
+    }
     uint32_t* __restrict__ off = (uint32_t*)(out + P.out_off);
     uint32_t* __restrict__ srcoff = (uint32_t*)(scratch + P.s_rows);
     const uint4* restarts = (const uint4*)(scratch + P.s_restart);

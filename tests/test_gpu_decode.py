@@ -322,6 +322,25 @@ def test_string_packs_of_mixed_dictionary_sizes_in_a_large_launch():
     check_cases(cases)
 
 
+def test_string_pack_that_announces_a_wrong_dict_struct_size():
+    """The reference decodes the DictStruct into a buffer of the size the pack's first word announces: a smaller figure
+    fails (BUFFER_OVERFLOW), a larger one is accepted.  Found by tools/soak.py as a one-bit flip the decoder let through."""
+    r = rng(3)
+    few = [b"www.s%d.com/%d" % (i % 5, i % 4) for i in range(200)]                 # plain entries
+    many = [b"www.s%d.com/%d" % (i % 37, i % 500) for i in r.integers(0, 5000, 9000)]  # front-coded entries
+    cases = []
+    for rows in (few, many):
+        c = oracle_case(rows, L.STRING, O.DICT_COMPRESS)
+        size = int(c.pack[:4].view("<i4")[0])
+        for delta in (-8, -1, 1, 64):
+            q = c.pack.copy()
+            q[:4] = np.frombuffer(np.int32(size + delta).tobytes(), dtype=np.uint8)
+            dec, consumed = O.decompress_pack(q, c.data_type, c.encode_type, c.n, c.data_size)
+            assert (consumed == len(q)) == (delta > 0)
+            cases.append(Case(q, c.data_type, c.encode_type, c.n, c.data_size, dec if delta > 0 else None, "%s size%+d" % (c.name, delta)))
+    check_cases(cases)
+
+
 def test_bad_arguments():
     d = L.PackDesc(8, 0, 10, 40, 10, L.ENC_DELTA, L.INT, 0)  # misaligned in_off
     with pytest.raises(L.IxrError):
