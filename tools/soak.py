@@ -319,18 +319,86 @@ def filter_soak(args):
     print("filter soak ok: seed %d, %d batches, %d packs, %d rows, results %s, no difference" % (args.seed, batch, total, rows_total, dict(sorted(kinds.items()))))
 
 
+def aux_soak(args):
+    """the DictStruct batch form and the engine hand-back against the oracle"""
+    from indexr_amd import lib as L
+    from gpu_util import build_arena
+    t0 = time.time()
+    total = rows_total = 0
+    batch = 0
+    while time.time() - t0 < args.seconds:
+        r = np.random.default_rng([args.seed, 999, batch])
+        cases = []
+        for i in range(args.batch):
+            dt = int(r.choice([O.INT, O.LONG, O.FLOAT, O.DOUBLE, O.STRING], p=[.2, .3, .1, .15, .25]))
+            n = min(pick_n(r), 30000)
+            rows = strings(r, n) if dt == O.STRING else numbers(r, dt, n)
+            n = len(rows)
+            data = O.rows_to_bytes(rows, dt)
+            pack, et = O.compress_pack(data, dt, n, bool(r.integers(0, 2)))
+            dec, consumed = O.decompress_pack(pack, dt, et, n, len(data))
+            cases.append(Case(pack, dt, et, n, len(data), dec, "case %d type %d enc %d n %d" % (i, dt, et, n)))
+        descs, arena, out_bytes = build_arena(cases)
+        ds_off, off = [], 0
+        for c in cases:
+            ds_off.append(off)
+            off += (8 + c.data_size + 4 * c.n + 15) & ~15
+        hb, hoff = [], 0
+        for c, d in zip(cases, descs):
+            sql = {O.INT: [L.SQL_INT], O.LONG: [L.SQL_BIGINT, L.SQL_DATE, L.SQL_DATETIME, L.SQL_TIME], O.FLOAT: [L.SQL_FLOAT],
+                   O.DOUBLE: [L.SQL_DOUBLE], O.STRING: [L.SQL_VARCHAR]}[c.data_type]
+            ro = int(r.integers(0, c.n)) if r.random() < 0.5 else 0
+            rc = int(r.integers(0, c.n - ro + 1)) if r.random() < 0.5 else c.n - ro
+            h = L.HandbackDesc(d.out_off, hoff, c.n, c.data_size, int(r.choice(sql)), ro, rc, 0)
+            hb.append(h)
+            hoff += (int(L.lib.ixr_handback_bound(h)) + 15) & ~15
+        plan = L.Plan(0, descs)
+        d_in, d_out, d_ds, d_hb = L.DeviceBuffer(0, len(arena)), L.DeviceBuffer(0, out_bytes), L.DeviceBuffer(0, off + 16), L.DeviceBuffer(0, hoff + 16)
+        try:
+            d_in.upload(arena)
+            plan.run_dict_structs(d_in.ptr, len(arena), d_ds.ptr, off + 16, ds_off)
+            st_ds, _ = plan.status()
+            hds = d_ds.download()
+            plan.run(d_in.ptr, len(arena), d_out.ptr, out_bytes)
+            st, nbad = plan.status()
+            status, _ = L.handback_run(hb, d_out.ptr, out_bytes, d_hb.ptr, hoff + 16)
+            hhb = d_hb.download()
+        finally:
+            plan.destroy()
+            d_in.free(); d_out.free(); d_ds.free(); d_hb.free()
+        for i, (c, h) in enumerate(zip(cases, hb)):
+            where = "seed %d batch %d %s" % (args.seed, batch, c.name)
+            if st[i] != len(c.pack) or st_ds[i] != len(c.pack):
+                raise SystemExit("STATUS %s: %d / %d vs %d" % (where, st[i], st_ds[i], len(c.pack)))
+            if c.encode_type == O.DICT_COMPRESS:
+                want, consumed = O.get_dict_struct(c.pack, c.data_type, c.n)
+                if hds[ds_off[i]:ds_off[i] + len(want)].tobytes() != want.tobytes():
+                    raise SystemExit("DICT STRUCT DIFFERENCE %s" % where)
+            want, rr = O.handback(h.sql_type, c.n, c.expect, h.row_offset, h.row_count)
+            if int(status[i]) != rr or (rr > 0 and hhb[h.dst_off:h.dst_off + rr].tobytes() != want.tobytes()):
+                raise SystemExit("HAND-BACK DIFFERENCE %s sql %d rows [%d, +%d): %d vs %d" % (where, h.sql_type, h.row_offset, h.row_count, int(status[i]), rr))
+            rows_total += c.n
+        total += len(cases)
+        batch += 1
+        print("aux batch %d: %d packs so far, %d rows, %.0f s" % (batch, total, rows_total, time.time() - t0), flush=True)
+    print("DictStruct / hand-back soak ok: seed %d, %d batches, %d packs, %d rows, no difference" % (args.seed, batch, total, rows_total))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--batch", type=int, default=600)
     ap.add_argument("--encode", action="store_true", help="soak the device encoder instead of the decoder")
+    ap.add_argument("--aux", action="store_true", help="soak the DictStruct batch form and the engine hand-back instead of the decoder")
     ap.add_argument("--filter", action="store_true", help="soak the two predicate entry points and the row selection instead of the decoder")
     args = ap.parse_args()
     if args.encode:
         return encode_soak(args)
     if args.filter:
         return filter_soak(args)
+    if args.aux:
+        return aux_soak(args)
     t0 = time.time()
     total = mutated = failed_as_expected = rows = 0
     batch = 0
