@@ -389,6 +389,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=240)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--batch", type=int, default=600)
+    ap.add_argument("--scratch-mib", type=int, default=0, help="decoder soak: scratch budget of the plan (0 = default); a small one splits a batch into many groups")
     ap.add_argument("--encode", action="store_true", help="soak the device encoder instead of the decoder")
     ap.add_argument("--aux", action="store_true", help="soak the DictStruct batch form and the engine hand-back instead of the decoder")
     ap.add_argument("--filter", action="store_true", help="soak the two predicate entry points and the row selection instead of the decoder")
@@ -407,7 +408,7 @@ def main():
         cases = []
         for i in range(args.batch):
             cases += make_case(r, i)
-        outs, status, plan = run_batch(cases)
+        outs, status, plan = run_batch(cases, scratch_budget=args.scratch_mib << 20)
         plan.destroy()
         for c, out, st in zip(cases, outs, status):
             clean = not c.name.endswith("mutated")
