@@ -241,7 +241,7 @@ def filter_soak(args):
         cases, preds = [], []
         for i in range(args.batch):
             dt = int(r.choice([O.INT, O.LONG, O.FLOAT, O.DOUBLE, O.STRING], p=[.25, .2, .15, .15, .25]))
-            n = min(pick_n(r), 20000)
+            n = min(pick_n(r), args.max_rows)
             rows = strings(r, n) if dt == O.STRING else numbers(r, dt, n)
             if dt in (O.FLOAT, O.DOUBLE):
                 rows = np.where(np.isnan(rows), 1.25, rows).astype(NUM[dt])  # binary search over NaN entries: not exercised here
@@ -390,6 +390,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--batch", type=int, default=600)
     ap.add_argument("--scratch-mib", type=int, default=0, help="decoder soak: scratch budget of the plan (0 = default); a small one splits a batch into many groups")
+    ap.add_argument("--max-rows", type=int, default=20000, help="filter soak: largest pack")
     ap.add_argument("--encode", action="store_true", help="soak the device encoder instead of the decoder")
     ap.add_argument("--aux", action="store_true", help="soak the DictStruct batch form and the engine hand-back instead of the decoder")
     ap.add_argument("--filter", action="store_true", help="soak the two predicate entry points and the row selection instead of the decoder")
