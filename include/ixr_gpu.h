@@ -11,7 +11,11 @@
  *     (indexr-vlt-segment/.../codec/Decoder.java:3-25, .../codec/ErrorCode.java:4-7); the caller checks
  *     consumed == dpn.packSize exactly as PackCompressor_VLT.decompress does (:168);
  *   - the caller allocates the output of exactly dpn.dataSize bytes (PackCompressor_VLT.java:133).
- * All entry points are thread-safe and re-entrant; state is per plan / per call.
+ * Threading: entry points may be called from any number of threads, and different plans are independent of each other.
+ * ONE plan supports one run at a time: ixr_plan_run, ixr_plan_run_dict_structs, ixr_plan_run_filter and ixr_plan_status
+ * of the same plan share its scratch memory, its device copy of the descriptors, its auxiliary stream and its result
+ * records, so the caller orders them (same stream, or a synchronisation between runs on different streams) and never
+ * calls them on one plan from two threads at once.  The reference has the same rule per DataPack (DPSegment.java:52).
  */
 #ifndef IXR_GPU_H
 #define IXR_GPU_H
@@ -128,8 +132,11 @@ int32_t   ixr_plan_kernel_bytes(ixr_plan* plan, uint64_t* alg_bytes, int32_t cap
 /* ---- dictionary form on device ------------------------------------------------------------------------------------
  * Replaces PackCompressor_VLT.getDictStruct (:172-186) for every DICT_COMPRESS pack of the plan: writes the
  * uncompressed DictStruct (indexr-common/.../data/DictStruct.java:14-55:  entryCount | entries | 4n | ids) of pack i at
- * d_out + ds_off[i]; ds_off are byte offsets supplied by the caller (multiples of IXR_ARENA_ALIGN), each region holding
- * at least the pack's dictStructSize (its first 4 bytes).  Packs of other encodings are skipped.
+ * d_out + ds_off[i]; ds_off are byte offsets supplied by the caller (multiples of IXR_ARENA_ALIGN).  The DictStruct's own
+ * size (dictStructSize, the pack's first 4 bytes) is only known on the device, so the region of a DICT_COMPRESS pack must
+ * hold the largest DictStruct its descriptor allows, 8 + data_size + 4 * obj_count bytes, inside the arena; the call
+ * rejects anything smaller.  Packs of other encodings are skipped: nothing of them is decoded or written, their ds_off
+ * entries are not looked at beyond the alignment check (0 is fine), and the arena needs no room for them.
  */
 int32_t   ixr_plan_run_dict_structs(ixr_plan* plan, const void* d_in, uint64_t in_bytes, void* d_out, uint64_t out_bytes,
                                     const uint64_t* ds_off, void* stream);

@@ -479,6 +479,9 @@ extern "C" int32_t ixr_plan_run_dict_structs(ixr_plan* pl, const void* d_in, uin
     pl->event_used = 0;
     Timer T{pl, st};
     LaunchCtx c{st, pl->d_packs, pl->d_metas, (const uint8_t*)d_in, (uint8_t*)d_out, pl->d_scratch};
+    // Only DICT_COMPRESS packs have a region in this arena: packs that decode straight to `out_off` (DELTA numbers,
+    // front-coded string packs) are skipped by every kernel, dictionaries are built in scratch only.
+    c.dict_only = 1;
     const int* L = pl->d_lists;
     run_parse_all(pl, T, c);
     for (const Group& g : pl->groups) {
@@ -639,6 +642,9 @@ static int32_t single_pack(int32_t device, int32_t data_type, int32_t encode_typ
             const int w = (data_type == IXR_INT || data_type == IXR_FLOAT) ? 4 : 8;
             if ((int64_t)obj_count * w > out_limit) return fail(IXR_ERR_BUFFER_OVERFLOW, "output too small");
             d.data_size = obj_count * w;
+        } else if ((int64_t)out_limit < 4 * ((int64_t)obj_count + 1)) {
+            // the row index alone does not fit: StringsStruct.Builder would run off the buffer (DictStruct.java:97-110)
+            return fail(IXR_ERR_BUFFER_OVERFLOW, "output too small for the index of %d strings", obj_count);
         }
         dict_cap_override = (uint64_t)in_size;
     }

@@ -965,14 +965,15 @@ extern "C" int32_t ixr_encode_run(int32_t device, ixr_encode_desc* descs, int32_
     if (scratch_budget < per_pack_max) return set_error(IXR_ERR_INVALID_ARGUMENT, "scratch budget smaller than one pack needs");
     if (hipSetDevice(device) != hipSuccess) return set_error(IXR_ERR_HIP, "hipSetDevice failed");
     hipStream_t st = (hipStream_t)stream;
-    // groups of packs whose scratch fits the budget
+    // groups of packs whose scratch fits the budget; a group is also the y extent of the per-pack grids, which ends at 65535
+    constexpr int kMaxGroupPacks = 32768;
     struct Group { int first, count; uint64_t bytes; };
     std::vector<Group> groups;
     uint64_t max_group = 0;
     for (int i = 0; i < n;) {
         uint64_t bytes = 0;
         int j = i;
-        while (j < n && bytes + need[(size_t)j] <= scratch_budget) bytes += need[(size_t)j++];
+        while (j < n && j - i < kMaxGroupPacks && bytes + need[(size_t)j] <= scratch_budget) bytes += need[(size_t)j++];
         groups.push_back({i, j - i, bytes});
         max_group = std::max(max_group, bytes);
         i = j;
@@ -1014,7 +1015,8 @@ extern "C" int32_t ixr_encode_run(int32_t device, ixr_encode_desc* descs, int32_
         gp.k64_in = off; off += align256(e64 * 8);
         gp.k64_out = off; off += align256(e64 * 8);
         for (int i = g.first; i < g.first + g.count; i++) off = layout_pack(hp[(size_t)i], off);
-        if (off > max_group + 256 + 4 * 256) return set_error(IXR_ERR_BUG, "encode scratch layout exceeds its allocation");
+        // the key areas round up once each where `need` rounded up once per pack: the layout never exceeds the group's sum
+        if (off > max_group) return set_error(IXR_ERR_BUG, "encode scratch layout exceeds its allocation");
         // temporary storage of the sort: the largest any group asks for
         size_t t = 0;
         if (gp.c32 && sort_segments<uint32_t>(nullptr, t, (uint32_t*)nullptr, (uint32_t*)nullptr, gp.t32, (unsigned)gp.c32, (const unsigned*)nullptr, (const unsigned*)nullptr, st) != hipSuccess)
@@ -1026,7 +1028,6 @@ extern "C" int32_t ixr_encode_run(int32_t device, ixr_encode_desc* descs, int32_
         temp_bytes = std::max(temp_bytes, t);
         plans.push_back(gp);
     }
-    // the key areas are aligned to 256 each: four roundings more than `need` accounts for
     if (!d_temp.alloc(temp_bytes + 256)) return set_error(IXR_ERR_OUT_OF_MEMORY, "hipMalloc failed");
     if (hipMemcpyAsync(d_packs.p, hp.data(), sizeof(EncPack) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess ||
         hipMemcpyAsync(d_metas.p, hm.data(), sizeof(EncMeta) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess ||

@@ -1910,6 +1910,7 @@ __global__ __launch_bounds__(256) void k_ds_rows(const DevPack* __restrict__ pac
     } else if constexpr (MODE == 1) {
         ((uint64_t*)(out + P.out_off))[i] = ((const uint64_t*)(scratch + P.s_dict))[id];
     } else {
+        if (4ull * (n + 1) > (uint64_t)P.data_size) return;  // no room for the index: k_row_scan reports the overflow
         const uint32_t* doff = (const uint32_t*)(scratch + P.s_dict);
         const uint32_t a = doff[id], b = doff[id + 1];
         ((uint32_t*)(out + P.out_off))[i + 1] = b - a;

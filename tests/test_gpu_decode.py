@@ -214,6 +214,68 @@ def test_dict_structs_batch():
     plan.destroy(); d_in.free(); d_out.free()
 
 
+def test_dict_structs_mixed_plan_arena_holds_dictionary_packs_only():
+    """Packs without a DictStruct (DELTA numbers, front-coded string packs, SIMPLE_DICT) are skipped: they get no room in
+    the arena and ds_off 0, and nothing of them may be written anywhere.  A small scratch budget splits the plan into
+    several groups, so a stray decode of a later group would land on DictStructs an earlier group produced."""
+    from gpu_util import build_arena, align16
+    r = rng(77)
+    cases = []
+    for rep in range(6):
+        cases.append(oracle_case(np.cumsum(r.integers(0, 9, size=65536)).astype("<i4"), O.INT, O.DELTA, name="int delta %d" % rep))
+        cases.append(oracle_case(_strings(r, 3000), O.STRING, O.DELTA, name="str delta %d" % rep))
+        cases.append(oracle_case(_column(r, O.LONG, 30000, 500), O.LONG, O.DICT_COMPRESS, name="long dict %d" % rep))
+        cases.append(oracle_case(_strings(r, 20000), O.STRING, O.DICT_COMPRESS, name="str dict %d" % rep))
+        cases.append(oracle_case(_column(r, O.FLOAT, 2000, 50), O.FLOAT, O.SIMPLE_DICT, name="float simple %d" % rep))
+        cases.append(oracle_case(_column(r, O.DOUBLE, 65536, 40000), O.DOUBLE, O.DICT_COMPRESS, name="double dict %d" % rep))
+    descs, arena, _ = build_arena(cases)
+    ds_off, off = [], 0
+    for c in cases:
+        if c.encode_type == O.DICT_COMPRESS:
+            ds_off.append(off)
+            off += align16(8 + c.data_size + 4 * c.n)
+        else:
+            ds_off.append(0)
+    guard = 4096
+    fill = 0xA7
+    for budget in (0, 3 << 20):
+        plan = L.Plan(0, descs, budget)
+        d_in = L.DeviceBuffer(0, len(arena)); d_out = L.DeviceBuffer(0, off + guard)
+        d_in.upload(arena)
+        d_out.upload(np.full(off + guard, fill, dtype=np.uint8))
+        plan.run_dict_structs(d_in.ptr, len(arena), d_out.ptr, off, ds_off)
+        status, _ = plan.status()
+        host = d_out.download()
+        assert (host[off:] == fill).all(), "bytes after the arena were written"
+        for c, o, st in zip(cases, ds_off, status):
+            assert st == len(c.pack), c.name
+            if c.encode_type != O.DICT_COMPRESS:
+                continue
+            ds_o, c_o = O.get_dict_struct(c.pack, c.data_type, c.n)
+            assert c_o == len(c.pack)
+            assert host[o:o + len(ds_o)].tobytes() == ds_o.tobytes(), "%s (scratch budget %d)" % (c.name, budget)
+        plan.destroy(); d_in.free(); d_out.free()
+
+
+def test_rows_from_dict_struct_with_an_output_too_small_for_the_index():
+    """DictStruct.decodeStrings into a buffer that cannot even hold the row index: BUFFER_OVERFLOW, nothing written
+    past the caller's buffer (PackCompressor_VLT.getDataFromDictStruct :188-213)."""
+    r = rng(78)
+    rows = _strings(r, 65536)
+    data = O.rows_to_bytes(rows, O.STRING)
+    pack, et = O.compress_pack(data, O.STRING, 65536, False)
+    ds, consumed = O.get_dict_struct(pack, O.STRING, 65536)
+    assert consumed == len(pack)
+    for limit in (16, 4 * 65536, 4 * 65537 - 1):
+        out, w = L.get_data_from_dict_struct(ds, O.STRING, 65536, limit)
+        assert w == L.ERR_BUFFER_OVERFLOW, (limit, w)
+    # the index fits, the body does not
+    out, w = L.get_data_from_dict_struct(ds, O.STRING, 65536, 4 * 65537 + 10)
+    assert w == L.ERR_BUFFER_OVERFLOW
+    out, w = L.get_data_from_dict_struct(ds, O.STRING, 65536, len(data))
+    assert w == len(data) and out.tobytes() == data.tobytes()
+
+
 def _corrupt_variants(case, r):
     out = []
     p = case.pack

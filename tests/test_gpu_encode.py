@@ -301,3 +301,28 @@ def test_gpu_encoder_rejects_descriptors_that_leave_the_arenas():
     finally:
         d_data.free()
         d_out.free()
+
+
+@pytest.mark.gpu
+def test_more_packs_than_a_grid_dimension_holds():
+    """70000 one-row packs in one call: groups are capped by pack count as well as by scratch, since a group is the y
+    extent of the per-pack launches."""
+    n = 70000
+    rng = np.random.default_rng(5)
+    vals = rng.integers(-1000, 1000, n).astype("<i4")
+    d_data = L.DeviceBuffer(0, 16 * n)
+    host = np.zeros(16 * n, dtype=np.uint8)
+    host.view("<i4")[::4] = vals
+    d_data.upload(host)
+    slot = (L.lib.ixr_compress_bound(1, 4) + 15) & ~15
+    descs = [L.EncodeDesc(16 * i, slot * i, O.INT, 0, 1, 4, 0, 0, 0, 0, 0) for i in range(n)]
+    d_out = L.DeviceBuffer(0, slot * n)
+    arr, bad = L.encode_run(descs, d_data.ptr, 16 * n, d_out.ptr, slot * n)
+    assert bad == 0
+    out = d_out.download()
+    for i in list(range(0, n, 997)) + [32767, 32768, 65535, 65536, n - 1]:
+        want, et = O.compress_pack(vals[i:i + 1].view(np.uint8), O.INT, 1, False)
+        assert arr[i].encode_type == et and arr[i].pack_size == len(want)
+        assert out[slot * i:slot * i + len(want)].tobytes() == want.tobytes()
+        assert arr[i].min_value == arr[i].max_value == arr[i].sum == int(vals[i])
+    d_data.free(); d_out.free()
