@@ -1,16 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- device-resident IndexR VLT pack decode on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU.  Run as it stands, the script starts the N ranks itself (children, before anything touches a
+GPU); under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.
 
 Workload (config.workload): BASELINE.json's mixed-type table -- columns INT (1000 categories), LONG (ms timestamps),
-FLOAT (k/10, 10 000 values), DOUBLE (k/10, 50 000 values), VARCHAR (Zipf over 50 000 URLs) -- `--rows` rows per GPU
+FLOAT (k/10, 10 000 values), DOUBLE (k/10, 50 000 values), VARCHAR (Zipf over 50 000 URLs) -- `--rows` rows
 (default 1 000 000 000 = 15 259 packs per column), generated pack by pack from (seed, column, pack id) and compressed
-with the library's host encoder (same codec choice as the reference's writer).  With N GPUs every rank decodes its own
-`--rows`-row range of pack ids of an N x rows table (packs are independent; no data-path collective), so per-GPU work is
-fixed: "scaling": "weak".
+with the library's host encoder (same codec choice as the reference's writer).
 
-A step = one ixr_plan_run over the whole table: compressed packs are already in HBM, decoded packs stay in HBM.
+Sharding (packs are independent, no data-path collective):
+  --scaling strong  (default for N > 1) the SAME `--rows`-row table; rank r decodes a contiguous range of pack ids, the
+                    ranges balanced by packSize + dataSize (SegmentAssigner.java:176-188 splits contiguously by count; string
+                    packs vary in size, so the cut points follow bytes)
+  --scaling weak    every rank decodes a `--rows`-row table of its own (pack ids [r * P, (r + 1) * P))
+
+A step = one ixr_plan_run over the rank's packs: compressed packs are already in HBM, decoded packs stay in HBM.
 Reported: decoded GB/s (sum of dpn.dataSize / time) over all ranks, rows/s, per-kernel device times from HIP events on the
 launch stream, the roofline of the dominant kernel and of the whole job, and the CPU oracle timed on a bounded sample.
 """
@@ -38,7 +45,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU")
+    ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows of the table (strong scaling) / of every rank's table (weak scaling)")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "strong", "weak"], help="auto: strong when N > 1")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the ranks (nccl = RCCL)")
+    ap.add_argument("--plan-only", action="store_true", help="build the tables, agree on the ranges, reduce the counters, print them; no GPU work (launcher and sharding tests on CPU)")
     ap.add_argument("--workload", default="mixed", choices=sorted(WORKLOADS))
     ap.add_argument("--kinds", default="", help="comma-separated synthetic column kinds (kernel experiments; overrides --workload)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xC0FFEE)
@@ -57,8 +67,44 @@ def parse_args():
     return ap.parse_args()
 
 
+def launch_ranks(n, argv):
+    """Starts the N ranks as child processes of this (GPU-free) process and waits for them: rank r gets RANK = LOCAL_RANK = r,
+    WORLD_SIZE = n and a rendezvous on 127.0.0.1.  Rank 0 inherits stdout (its JSON line is the run's output).  Returns the
+    exit code: 0 only if every rank exited with 0; when one fails the others are ended."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, pending = 0, set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print("[bench] rank %d exited with %d; ending the other ranks" % (r, code), file=sys.stderr, flush=True)
+                for q in pending:
+                    procs[q].terminate()
+        time.sleep(0.1)
+    return rc
+
+
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))  # nothing in this process has touched a GPU
     # Native libraries (RCCL's version banner, HIP warnings) write to file descriptor 1; the contract is ONE JSON line on
     # stdout.  Keep the real stdout aside and route everything else to stderr.
     sys.stdout.flush()
@@ -67,7 +113,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d: start one rank per GPU" % (args.gpus, world))
+    scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "weak")
     dist = None
+    tdev = "cpu"
     if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29513")
@@ -76,8 +126,17 @@ def main():
         # torch first: libixrgpu then binds to the HIP runtime torch bundles (same soname), one runtime per process.
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            tdev = "cuda"
+        else:
+            dist.init_process_group(backend="gloo")
+        # every rank is there: the sum of a 1 per rank over the collective is the number of GPUs asked for
+        one = torch.ones(1, dtype=torch.int64, device=tdev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        if int(one.item()) != args.gpus:
+            raise SystemExit("the collective saw %d ranks, --gpus says %d" % (int(one.item()), args.gpus))
     import numpy as np
 
     from indexr_amd import lib as L
@@ -85,19 +144,23 @@ def main():
     from indexr_amd import table as T
 
     device = local_rank if world > 1 else 0
-    rc = L.lib.ixr_init(device)
-    if rc != 0:
-        raise SystemExit("ixr_init(%d) failed: %s" % (device, L.lib.ixr_last_error().decode()))
+    if os.environ.get("IXR_BENCH_DEVICE"):  # rehearsals of N ranks on a box with fewer GPUs (with --backend gloo)
+        device = int(os.environ["IXR_BENCH_DEVICE"])
+    if not args.plan_only:
+        rc = L.lib.ixr_init(device)
+        if rc != 0:
+            raise SystemExit("ixr_init(%d) failed: %s" % (device, L.lib.ixr_last_error().decode()))
     threads = args.threads or int(os.environ.get("IXR_BENCH_THREADS", "0")) or max(1, min(16, int(os.environ.get("OMP_NUM_THREADS", "16"))))
     if threads == 1 and not args.threads:
         threads = 16  # torchrun exports OMP_NUM_THREADS=1 when it is unset
+    if world > 1 and not args.threads:
+        threads = max(2, min(threads, (os.cpu_count() or 16) // world))  # the ranks build their inputs side by side
     desc_text, kinds = WORKLOADS[args.workload]
     if args.kinds:
         kinds = [int(k) for k in args.kinds.split(",")]
         desc_text = "experiment: synthetic column kinds %s" % kinds
     rows = args.rows
     n_packs = T.pack_count(rows)  # DataPack.rowCountToPackCount (DataPack.java:773-803)
-    first_pack = S.weak_scaling_first_pack(rank, n_packs)  # this rank's contiguous range of pack ids
 
     def log(msg):
         if rank == 0:
@@ -105,12 +168,34 @@ def main():
 
     # ------------------------------------------------------------------ build the compressed table, chunk by chunk
     t0 = time.time()
-    table = T.build_table(kinds, rows, first_pack, args.seed, threads=threads, log=log)
+    ranges = None
+    if scaling == "weak":
+        # a table of its own per rank: the content of pack ids [rank * P, (rank + 1) * P)
+        table = T.build_table(kinds, rows, S.weak_scaling_first_pack(rank, n_packs), args.seed, threads=threads, log=log)
+        my_first, my_count = 0, n_packs
+    else:
+        # the same table for any number of ranks.  Every rank first builds an equal count of pack ids (SegmentAssigner's
+        # split), the ranks exchange what each pack id weighs (packSize + dataSize over its columns: DataPackNode
+        # metadata), cut the table into byte-balanced contiguous ranges and build / drop the few pack ids at the cuts.
+        my_first, my_count = S.contiguous_range(n_packs, world, rank)
+        table = T.build_range(kinds, rows, my_first, my_count, args.seed, threads=threads, log=log)
+        if world > 1:
+            import torch
+            weights = T.gather_weights(dist, torch, tdev, n_packs, table.weights())
+            ranges = S.balanced_ranges(weights, world)
+            my_first, my_count = ranges[rank]
+            T.retarget(table, kinds, rows, my_first, my_count, args.seed, threads=threads)
     all_descs, host_chunks, sums, sample_for_cpu = table.descs, table.chunks, table.sums, table.sample
     in_bytes, out_bytes = table.in_bytes, table.out_bytes
     in_off = in_bytes - L.IN_SLACK
     log("input built in %.1f s with %d threads: %d packs, %.2f GB compressed -> %.2f GB decoded"
         % (time.time() - t0, threads, len(all_descs), in_off / 1e9, (out_bytes - 16) / 1e9))
+    if not all_descs:
+        raise SystemExit("rank %d got no packs: %d pack ids do not split over %d ranks" % (rank, n_packs, world))
+
+    if args.plan_only:
+        plan_only(args, T, dist, tdev, world, rank, scaling, ranges, (my_first, my_count), table, n_packs, real_stdout)
+        return
 
     # ------------------------------------------------------------------ move to HBM, plan
     d_in = L.DeviceBuffer(device, in_bytes)
@@ -156,7 +241,7 @@ def main():
         import torch
         # max-over-ranks time and the optional gather of decoded row counts: 4 counters per rank over RCCL
         elapsed, (tot_rows, tot_out, tot_in, bad_all) = T.reduce_over_ranks(
-            dist, torch, "cuda", elapsed, [plan.total_rows, plan.total_out, plan.total_in, bad])
+            dist, torch, tdev, elapsed, [plan.total_rows, plan.total_out, plan.total_in, bad])
     else:
         tot_rows, tot_out, tot_in, bad_all = plan.total_rows, plan.total_out, plan.total_in, bad
     if bad_all:
@@ -209,12 +294,14 @@ def main():
         per_launch = dom["alg_bytes_per_step"] * args.steps / max(dom["launches"], 1)
         achieved = per_launch / (dom["avg_ms"] / 1e3) / 1e9 if dom["avg_ms"] > 0 else 0.0
         whole = (plan.total_in + plan.total_out) * args.steps / elapsed / 1e9
-        traffic, traffic_src = pmc_traffic(dom["name"], "%s, %d rows per GPU" % (desc_text, rows), dom["launches"] / args.steps)
+        workload_text = workload_name(desc_text, rows, n_packs, len(kinds), world, scaling)
+        traffic, traffic_src, traffic_all = pmc_traffic(dom["name"], workload_text, dom["launches"] / args.steps, len(all_descs))
         roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "alg_bytes_per_launch": int(per_launch), "avg_launch_ms": dom["avg_ms"],
                     "whole_job": {"achieved": round(whole, 1), "frac": round(whole / HBM_PEAK_GBS, 4),
                                   "alg_bytes_per_step": plan.total_in + plan.total_out,
+                                  "traffic": traffic_all,  # HBM bytes of one pass, all kernels (same counter file)
                                   "device_ms_per_step": round(tot_ms / args.steps, 3)}}
         if dom["name"] in exclusive:
             ems, el, ealg = exclusive[dom["name"]]
@@ -254,7 +341,7 @@ def main():
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, bounded sample)
     cpu_baseline = None
-    if rank == 0 and args.cpu_seconds > 0:
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
         cpu_baseline = time_cpu_oracle(np, sample_for_cpu, threads, args.cpu_seconds, log)
 
     if rank == 0:
@@ -267,13 +354,17 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "u8/u32/u64 (integer and byte moves; float/double handled as bit patterns)",
             "data": "synthetic (deterministic per (seed, column, pack id); compressed by the library's host encoder)",
-            "config": {"workload": "%s, %d rows per GPU (%d packs x %d columns per GPU)" % (desc_text, rows, n_packs, len(kinds)),
-                       "rows_per_gpu": rows, "packs_per_gpu": len(all_descs), "parallelism": "packs sharded by pack id over %d GPU(s), no collective" % world,
-                       "compressed_GB_per_gpu": round(plan.total_in / 1e9, 3), "decoded_GB_per_gpu": round(plan.total_out / 1e9, 3)},
+            "config": {"workload": workload_name(desc_text, rows, n_packs, len(kinds), world, scaling),
+                       "rows": rows if scaling == "strong" else rows * world, "rows_on_rank0": plan.total_rows // len(kinds),
+                       "packs_on_rank0": len(all_descs),
+                       "parallelism": "packs sharded by pack id over %d GPU(s) (%s), no data-path collective" % (
+                           world, "one table, contiguous byte-balanced ranges" if scaling == "strong" else "one table per GPU"),
+                       "pack_id_ranges": [list(r) for r in ranges] if ranges else [[0, n_packs]],
+                       "compressed_GB": round(tot_in / 1e9, 3), "decoded_GB": round(tot_out / 1e9, 3)},
             "rows_per_s": round(rows_per_s, 1),
             "compression_ratio": round(plan.total_in / plan.total_out, 4),
             "verified_bit_exact": verified,
@@ -302,23 +393,57 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(kernel, workload_prefix, launches_per_pass):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes (hardware counters cannot be read from
-    inside this process; tools/profile.sh + tools/pmc_traffic.py produce the file).  None unless the file was measured on
-    this very workload."""
+def workload_name(desc_text, rows, n_packs, n_cols, world, scaling):
+    if scaling == "strong":
+        return "%s, %d rows (%d packs x %d columns) over %d GPU(s)" % (desc_text, rows, n_packs, n_cols, world)
+    return "%s, %d rows per GPU (%d packs x %d columns per GPU)" % (desc_text, rows, n_packs, n_cols)
+
+
+def pmc_traffic(kernel, workload, launches_per_pass, n_packs):
+    """HBM bytes per launch of `kernel`, and of one whole pass, from the committed rocprofv3 counter passes (hardware
+    counters cannot be read from inside this process; tools/profile.sh + tools/pmc_traffic.py produce the file).  Both
+    are None unless the file was measured on this very workload AND on these very kernel sources: the file carries a
+    hash of indexr_amd/csrc, and a counter file of other kernels says nothing about the ones that just ran."""
+    from indexr_amd import provenance
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as fh:
             doc = json.load(fh)
     except (OSError, ValueError):
-        return None, None
-    if not str(doc.get("workload", "")).startswith(workload_prefix):
-        return None, None
+        return None, None, None
+    # one GPU's counters: the same column mix and pack count, whatever the file's run called its sharding
+    if doc.get("csrc_hash") != provenance.csrc_hash() or doc.get("packs") != n_packs or \
+            str(doc.get("workload", "")).split(",")[0] != workload.split(",")[0]:
+        return None, None, None
     k = doc.get("kernels", {}).get(kernel)
     if not k or not k.get("hbm_bytes_per_pass") or launches_per_pass <= 0:
-        return None, None
+        return None, None, None
+    total = sum(v.get("hbm_bytes_per_pass") or 0 for v in doc["kernels"].values())
     # the counters were summed over one pass of the table; this run may split the pass into a different number of launches
-    return int(k["hbm_bytes_per_pass"] / launches_per_pass), "profiles/pmc_traffic.json (%s)" % doc.get("source", "")
+    return int(k["hbm_bytes_per_pass"] / launches_per_pass), "profiles/pmc_traffic.json (%s)" % doc.get("source", ""), int(total)
+
+
+def plan_only(args, T, dist, tdev, world, rank, scaling, ranges, mine, table, n_packs, real_stdout):
+    """--plan-only: everything of a run that needs no GPU.  The ranks have built their tables and agreed on the ranges; reduce
+    the counters as the timed run does and let rank 0 print what all ranks hold together.  The expected pack checksums are
+    summed in two 32-bit halves (a size-independent fingerprint of the packs held, free of 64-bit overflow)."""
+    import numpy as np
+    sums = np.asarray(table.sums, dtype=np.uint64)
+    counters = [sum(d.obj_count for d in table.descs), sum(d.data_size for d in table.descs), sum(d.pack_size for d in table.descs),
+                int((sums & np.uint64(0xFFFFFFFF)).sum()), int((sums >> np.uint64(32)).sum()), len(table.descs)]
+    if dist is not None:
+        import torch
+        _, counters = T.reduce_over_ranks(dist, torch, tdev, 0.0, counters)
+    if rank == 0:
+        real_stdout.write(json.dumps({
+            "metric": "device-resident pack decode GB/s (decoded bytes)", "value": None, "unit": "GB/s", "n_gpus": world,
+            "plan_only": True, "scaling": scaling,
+            "pack_id_ranges": [list(r) for r in ranges] if ranges else [[0, n_packs]],
+            "rows": counters[0], "decoded_bytes": counters[1], "compressed_bytes": counters[2],
+            "checksum_halves": [counters[3], counters[4]], "packs": counters[5]}) + "\n")
+        real_stdout.flush()
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def time_cpu_oracle(np, sample, threads, target_s, log):

@@ -10,9 +10,13 @@ stores.  Both passes run the same command, so dispatches are matched by kernel n
 import csv
 import glob
 import json
+import os
 import re
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from indexr_amd import provenance  # noqa: E402
 
 
 PASSES = 3  # decode passes in one counter run of tools/profile.sh
@@ -72,7 +76,11 @@ def main():
     doc = {
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); read = 2 * FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB",
         "workload": bench["config"]["workload"] if bench else None,
-        "rows_per_gpu": bench["config"]["rows_per_gpu"] if bench else None,
+        "packs": bench["config"]["packs_on_rank0"] if bench else None,
+        # the kernels these counters belong to: bench.py quotes the file only while indexr_amd/csrc still hashes to this
+        "csrc_hash": provenance.csrc_hash(),
+        "launches_per_pass": {k: v["launches_counted"] / PASSES for k, v in kernels.items()},
+        "hbm_bytes_per_pass_all_kernels": sum(v["hbm_bytes_per_pass"] for v in kernels.values()),
         "kernels": kernels,
     }
     with open(out, "w") as fh:
