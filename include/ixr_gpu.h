@@ -129,6 +129,28 @@ int32_t   ixr_plan_kernel_times(ixr_plan* plan, const char** names, float* ms, i
  * memory is not counted. */
 int32_t   ixr_plan_kernel_bytes(ixr_plan* plan, uint64_t* alg_bytes, int32_t cap);
 
+/* ---- batch decode that allocates nothing ----------------------------------------------------------------------------
+ * No counterpart in the reference.  For callers that cannot allocate device memory at the point of the call: code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc.  Decodes 1..IXR_STATIC_MAX_PACKS packs exactly as
+ * ixr_plan_create + ixr_plan_run would (same kernels, same arenas, same results), but without a plan: the descriptors
+ * travel as a kernel argument and every working array (device records, framing indexes, decoded dictionaries, string
+ * offsets) lives in an array of IXR_STATIC_SCRATCH_BYTES that is part of the library's code object; each GPU the library
+ * runs on holds its copy until the process ends.  The call makes no hipMalloc / hipFree, creates no stream or event, and
+ * only enqueues kernels on `stream`.
+ *   d_status   device memory, n_packs x int32: receives what ixr_plan_status reports (bytes consumed or a negative error);
+ *              read it after synchronising with `stream`
+ * A batch whose working arrays exceed the array (about 5 MB per full VARCHAR pack of 3.6 MB, 0.6 MB per full numeric pack), or
+ * of more than IXR_STATIC_MAX_PACKS packs, is rejected with IXR_ERR_INVALID_ARGUMENT (ixr_last_error says how much it
+ * needs).  All calls on one GPU share that GPU's array, which keeps the last call's contents (the call clears what must
+ * start at zero): calls on the same GPU must not overlap -- order them on one stream or synchronise between them, two
+ * threads or two streams running it at once on one GPU race.  The first call on a device resolves the array's address
+ * (ixr_init does the same); call ixr_init beforehand where even that must not happen inside the critical section.
+ */
+#define IXR_STATIC_MAX_PACKS 64
+#define IXR_STATIC_SCRATCH_BYTES (32ull << 20)
+int32_t   ixr_decode_batch_static(int32_t device, const ixr_pack_desc* descs, int32_t n_packs, const void* d_in,
+                                  uint64_t in_bytes, void* d_out, uint64_t out_bytes, int32_t* d_status, void* stream);
+
 /* ---- dictionary form on device ------------------------------------------------------------------------------------
  * Replaces PackCompressor_VLT.getDictStruct (:172-186) for every DICT_COMPRESS pack of the plan: writes the
  * uncompressed DictStruct (indexr-common/.../data/DictStruct.java:14-55:  entryCount | entries | 4n | ids) of pack i at

@@ -53,6 +53,15 @@ extern "C" int32_t ixr_device_count(void) {
     return n;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Working memory of ixr_decode_batch_static, the entry point that allocates nothing: one array per GPU, part of the code
+// object, held by every GPU the library runs on until the process ends.  `static_scratch` is only a host-side handle of the
+// symbol; the array's device address is resolved once per device in ixr_init (hipGetSymbolAddress) and kept in
+// g_static_ptr, and that pointer is what kernels, memsets and copies get.
+// ---------------------------------------------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char static_scratch[IXR_STATIC_SCRATCH_BYTES];
+static std::atomic<uint8_t*> g_static_ptr[64];
+
 extern "C" int32_t ixr_init(int32_t device) {
     // the architecture check is remembered per device (querying the properties costs milliseconds); racing threads at
     // worst both do the query and store the same answer
@@ -69,7 +78,13 @@ extern "C" int32_t ixr_init(int32_t device) {
     HIP_TRY(hipGetDeviceProperties(&prop, device), return IXR_ERR_HIP);
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(IXR_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
-    if (device < 64) checked[device].store(1, std::memory_order_release);
+    if (device < 64) {
+        // this device's copy of the static scratch array (each GPU holds its own, at its own address)
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(static_scratch)), return IXR_ERR_HIP);
+        g_static_ptr[device].store((uint8_t*)p, std::memory_order_release);
+        checked[device].store(1, std::memory_order_release);
+    }
     return 0;
 }
 
@@ -191,41 +206,6 @@ struct ixr_plan {
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
-
-// Lays the scratch regions of one pack out from obj_count / data_size alone.  Two areas:
-//   index area (kept for the whole plan, filled by one k_parse launch over all packs): DELTA indexes, per-tile RLE segment records
-//   bulk area  (reused group after group): decoded dictionaries, string length arrays, per-row source offsets
-// Offsets are written relative to each area's start; the caller rebases them.  Returns the bytes used in each.
-struct ScratchNeed { uint64_t index, bulk; };
-static ScratchNeed pack_scratch_layout(DevPack& p, uint64_t dict_cap_override) {
-    uint64_t oi = 0, ob = 0;
-    const uint64_t cap = (uint64_t)p.obj_count;
-    const uint64_t idx = align16(8 * ((cap + kBlock - 1) / kBlock) + 4 * ((cap + kMini - 1) / kMini));
-    auto take_i = [&](uint64_t bytes) { uint64_t r = oi; oi += align16(bytes); return r; };
-    auto take_b = [&](uint64_t bytes) { uint64_t r = ob; ob += align16(bytes); return r; };
-    p.s_idx[0] = p.s_idx[1] = p.s_dict = p.s_restart = p.s_lens = p.s_rows = 0;
-    p.dict_cap = 0;
-    if (p.encode_type == IXR_ENC_RAW) return {0, 0};
-    p.s_idx[0] = take_i(idx);
-    const bool dict = p.encode_type == IXR_ENC_DICT_COMPRESS || p.encode_type == IXR_ENC_SIMPLE_DICT;
-    if (p.width) {
-        if (dict) {
-            p.dict_cap = dict_cap_override ? dict_cap_override : cap * (uint64_t)(p.width / 8);
-            p.s_dict = take_b(p.dict_cap + 16);
-            p.s_restart = take_i(16 * ((cap + kRleTile - 1) / kRleTile));
-        }
-    } else {
-        p.s_idx[1] = take_i(idx);
-        p.s_lens = take_b(4ull * 3 * lens_stride(p.obj_count));
-        if (dict) {
-            p.dict_cap = dict_cap_override ? dict_cap_override : (uint64_t)p.data_size;
-            p.s_dict = take_b(p.dict_cap + 32);
-            p.s_rows = take_b(4 * cap + 16);
-            p.s_restart = take_i(16 * ((cap + kRleTile - 1) / kRleTile));
-        }
-    }
-    return {oi, ob};
-}
 
 extern "C" void ixr_plan_destroy(ixr_plan* plan) {
     if (!plan) return;
@@ -489,6 +469,67 @@ extern "C" int32_t ixr_plan_run_dict_structs(ixr_plan* pl, const void* d_in, uin
         run_group_front_str(pl, T, c, g, 1);
         T.run("k_dict_struct", g.cnt[L_DICT], [&] { launch_dict_struct(c, L + g.off[L_DICT], g.cnt[L_DICT]); });
     }
+    HIP_TRY(hipGetLastError(), return IXR_ERR_HIP);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same decode for callers that cannot allocate: no hipMalloc / hipFree, no events, no second stream.  Descriptors go
+// to the device as a kernel argument; every working array lives in this GPU's static scratch array.
+// ---------------------------------------------------------------------------------------------------------------
+static_assert(sizeof(SmallDesc) == sizeof(ixr_pack_desc), "device and ABI descriptor layouts must match");
+static_assert(IXR_STATIC_MAX_PACKS == kStaticMaxPacks, "device code and the C ABI must agree on the batch limit");
+
+extern "C" int32_t ixr_decode_batch_static(int32_t device, const ixr_pack_desc* descs, int32_t n_packs, const void* d_in,
+                                           uint64_t in_bytes, void* d_out, uint64_t out_bytes, int32_t* d_status, void* stream) {
+    if (!descs || !d_in || !d_out || !d_status) return fail(IXR_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_packs < 1 || n_packs > IXR_STATIC_MAX_PACKS)
+        return fail(IXR_ERR_INVALID_ARGUMENT, "%d packs: this entry point takes 1..%d packs per call (use a plan for more)", n_packs, IXR_STATIC_MAX_PACKS);
+    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15) || ((uintptr_t)d_status & 3)) return fail(IXR_ERR_INVALID_ARGUMENT, "misaligned device pointer");
+    int32_t rc = ixr_init(device);
+    if (rc) return rc;
+    if (device >= 64) return fail(IXR_ERR_INVALID_ARGUMENT, "device %d: the static scratch is kept for devices 0..63", device);
+    uint8_t* block = g_static_ptr[device].load(std::memory_order_acquire);
+    if (!block) return fail(IXR_ERR_BUG, "static scratch of device %d was not resolved", device);
+    StaticBatch batch;
+    memset(&batch, 0, sizeof(batch));
+    batch.n = n_packs;
+    for (int i = 0; i < n_packs; i++) {
+        const ixr_pack_desc& d = descs[i];
+        if (d.pack_size < 0 || d.data_size < 0 || d.obj_count <= 0 || d.obj_count > IXR_PACK_MAX_ROWS ||
+            (d.in_off % IXR_ARENA_ALIGN) || (d.out_off % IXR_ARENA_ALIGN) || d.data_type < IXR_INT || d.data_type > IXR_STRING)
+            return fail(IXR_ERR_INVALID_ARGUMENT, "pack %d: bad descriptor (sizes, obj_count 1..65536, 16-byte aligned offsets, data type)", i);
+        if (d.in_off + (uint64_t)d.pack_size + IXR_IN_SLACK > in_bytes)
+            return fail(IXR_ERR_INVALID_ARGUMENT, "pack %d: the input arena must hold the pack and %d bytes of slack", i, IXR_IN_SLACK);
+        if (d.out_off + (uint64_t)d.data_size > out_bytes) return fail(IXR_ERR_INVALID_ARGUMENT, "pack %d: output outside the arena", i);
+        memcpy(&batch.d[i], &d, sizeof(SmallDesc));
+    }
+    int counts[SL_COUNT];
+    const uint64_t need = static_layout(batch.d, n_packs, nullptr, nullptr, counts);
+    if (need > IXR_STATIC_SCRATCH_BYTES)
+        return fail(IXR_ERR_INVALID_ARGUMENT, "the batch needs %llu bytes of working memory, the static scratch holds %llu: pass fewer packs per call",
+                    (unsigned long long)need, (unsigned long long)IXR_STATIC_SCRATCH_BYTES);
+    hipStream_t st = (hipStream_t)stream;
+    launch_static_setup(st, batch, block);
+    LaunchCtx c{st, (const DevPack*)block, (PackMeta*)(block + kStaticMetaOff), (const uint8_t*)d_in, (uint8_t*)d_out, block + kStaticHeader};
+    const int* lists = (const int*)(block + kStaticListOff);
+    const int *all = lists + SL_ALL * kStaticMaxPacks, *n32 = lists + SL_N32 * kStaticMaxPacks, *n64 = lists + SL_N64 * kStaticMaxPacks,
+              *str = lists + SL_STR * kStaticMaxPacks, *raw = lists + SL_RAW * kStaticMaxPacks;
+    launch_parse(c, all, counts[SL_ALL]);
+    launch_delta(c, n32, counts[SL_N32], 32, 1);
+    launch_delta(c, n64, counts[SL_N64], 64, 1);
+    launch_dict_num(c, n32, counts[SL_N32], 32);
+    launch_dict_num(c, n64, counts[SL_N64], 64);
+    launch_copy_raw(c, raw, counts[SL_RAW]);
+    launch_delta(c, str, counts[SL_STR], 32, 2);
+    launch_str_dict_scan(c, str, counts[SL_STR]);
+    launch_front_summary(c, str, counts[SL_STR], 0);
+    launch_front_combine(c, str, counts[SL_STR], 0);
+    launch_front_decode(c, str, counts[SL_STR], 0);
+    launch_front_serial(c, str, counts[SL_STR]);
+    launch_str_index(c, str, counts[SL_STR]);
+    launch_str_copy(c, str, counts[SL_STR]);
+    launch_export_status(st, c.metas, n_packs, d_status);
     HIP_TRY(hipGetLastError(), return IXR_ERR_HIP);
     return 0;
 }

@@ -51,6 +51,41 @@ struct DevPack {
     uint64_t ds_off;     // only for the getDictStruct run: where to write the DictStruct in the output arena
 };
 
+// Lays the scratch regions of one pack out from obj_count / data_size alone.  Two areas:
+//   index area (kept for a whole plan, filled by one parse launch over all packs): DELTA indexes, per-tile RLE segment records
+//   bulk area  (reused group after group): decoded dictionaries, string length arrays, per-row source offsets
+// Offsets are written relative to each area's start; the caller rebases them.  Returns the bytes used in each.
+struct ScratchNeed { uint64_t index, bulk; };
+__host__ __device__ inline uint64_t scratch_align16(uint64_t v) { return (v + 15) & ~15ull; }
+__host__ __device__ inline ScratchNeed pack_scratch_layout(DevPack& p, uint64_t dict_cap_override) {
+    uint64_t oi = 0, ob = 0;
+    const uint64_t cap = (uint64_t)p.obj_count;
+    const uint64_t idx = scratch_align16(8 * ((cap + kBlock - 1) / kBlock) + 4 * ((cap + kMini - 1) / kMini));
+    const uint64_t restart = 16 * ((cap + kRleTile - 1) / kRleTile);
+    p.s_idx[0] = p.s_idx[1] = p.s_dict = p.s_restart = p.s_lens = p.s_rows = 0;
+    p.dict_cap = 0;
+    if (p.encode_type == 0 /* stored uncompressed */) return {0, 0};
+    p.s_idx[0] = oi; oi += idx;
+    const bool dict = p.encode_type == 6 /* DICT_COMPRESS */ || p.encode_type == 4 /* SIMPLE_DICT */;
+    if (p.width) {
+        if (dict) {
+            p.dict_cap = dict_cap_override ? dict_cap_override : cap * (uint64_t)(p.width / 8);
+            p.s_dict = ob; ob += scratch_align16(p.dict_cap + 16);
+            p.s_restart = oi; oi += restart;
+        }
+    } else {
+        p.s_idx[1] = oi; oi += idx;
+        p.s_lens = ob; ob += scratch_align16(4ull * 3 * lens_stride(p.obj_count));
+        if (dict) {
+            p.dict_cap = dict_cap_override ? dict_cap_override : (uint64_t)p.data_size;
+            p.s_dict = ob; ob += scratch_align16(p.dict_cap + 32);
+            p.s_rows = ob; ob += scratch_align16(4 * cap + 16);
+            p.s_restart = oi; oi += restart;
+        }
+    }
+    return {oi, ob};
+}
+
 struct StreamDesc {
     uint32_t n;       // values in the stream (0 = absent)
     uint32_t in_off;  // offset of the stream's 4-byte length word, relative to the pack

@@ -2512,6 +2512,29 @@ __global__ __launch_bounds__(256) void k_checksum(const DevPack* __restrict__ pa
     if (threadIdx.x == 0) sums[pi] = part[0] + part[1] + part[2] + part[3];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The batch that allocates nothing: its descriptors arrive as a kernel argument, one thread turns them into the device
+// records the decode kernels read (the same layout function the host used for its bound check).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_static_setup(StaticBatch batch, uint8_t* block) {
+    DevPack* packs = (DevPack*)block;
+    PackMeta* metas = (PackMeta*)(block + kStaticMetaOff);
+    int* lists = (int*)(block + kStaticListOff);
+    static_assert(sizeof(DevPack) * kStaticMaxPacks <= kStaticMetaOff, "records overlap");
+    static_assert(kStaticMetaOff + sizeof(PackMeta) * kStaticMaxPacks <= kStaticListOff, "records overlap");
+    static_assert(kStaticListOff + sizeof(int) * SL_COUNT * kStaticMaxPacks <= kStaticHeader, "records overlap");
+    // the last call's results must not be mistaken for this call's: every record starts at zero
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(sizeof(PackMeta) * kStaticMaxPacks / 4); i += blockDim.x) ((uint32_t*)metas)[i] = 0;
+    if (threadIdx.x == 0) {
+        int counts[SL_COUNT];
+        static_layout(batch.d, batch.n, packs, lists, counts);
+    }
+}
+__global__ void k_export_status(const PackMeta* __restrict__ metas, int count, int32_t* __restrict__ d_status) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) d_status[i] = metas[i].status;
+}
+
 // ===============================================================================================================
 // launchers
 // ===============================================================================================================
@@ -2633,6 +2656,13 @@ void launch_handback(hipStream_t stream, const HandbackDesc* descs, int count, c
 void launch_checksum(const LaunchCtx& c, int count, unsigned long long* sums) {
     if (count <= 0) return;
     hipLaunchKernelGGL(k_checksum, dim3(count), dim3(256), 0, c.stream, c.packs, count, c.out, sums);
+}
+void launch_static_setup(hipStream_t stream, const StaticBatch& batch, uint8_t* block) {
+    hipLaunchKernelGGL(k_static_setup, dim3(1), dim3(64), 0, stream, batch, block);
+}
+void launch_export_status(hipStream_t stream, const PackMeta* metas, int count, int32_t* d_status) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_export_status, dim3(cdiv((unsigned)count, 64)), dim3(64), 0, stream, metas, count, d_status);
 }
 void launch_dict_struct(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;

@@ -20,6 +20,59 @@ struct LaunchCtx {
     int dict_only = 0;     // 1: build dictionaries only; packs whose decode writes straight to the output arena are skipped
 };
 
+// ---- the batch that allocates nothing: descriptors travel as a kernel argument, every working array lives in one
+// caller-supplied block of device memory (the library's static scratch array), laid out as
+//   [DevPack x kStaticMaxPacks][PackMeta x kStaticMaxPacks][5 work lists x kStaticMaxPacks ints] | index area | bulk area
+constexpr int kStaticMaxPacks = 64;
+constexpr uint64_t kStaticMetaOff = 8192, kStaticListOff = 16384, kStaticHeader = 32768;
+enum StaticList { SL_ALL = 0, SL_N32, SL_N64, SL_STR, SL_RAW, SL_COUNT };
+struct SmallDesc {  // same layout as ixr_pack_desc
+    uint64_t in_off, out_off;
+    int32_t pack_size, data_size, obj_count, encode_type, data_type, reserved;
+};
+struct StaticBatch {
+    SmallDesc d[kStaticMaxPacks];
+    int32_t n;
+};
+// Lays the batch out behind the header; fills `packs` (offsets relative to the block's start + kStaticHeader), the work lists
+// (`lists[c * kStaticMaxPacks + k]`) and their lengths when the pointers are given.  Returns the bytes of the block the batch
+// needs.  Runs on the host (bound check, grid sizes) and on the device (the records themselves) with the same result.
+__host__ __device__ inline uint64_t static_layout(const SmallDesc* d, int n, DevPack* packs, int* lists, int* counts) {
+    uint64_t index_total = 0;
+    for (int i = 0; i < n; i++) {
+        DevPack p;
+        p.obj_count = d[i].obj_count; p.data_size = d[i].data_size; p.encode_type = d[i].encode_type;
+        p.width = (d[i].data_type == 1 || d[i].data_type == 3) ? 32 : (d[i].data_type == 5 ? 0 : 64);
+        index_total += pack_scratch_layout(p, 0).index;
+    }
+    index_total = scratch_align16(index_total) + 64;  // the bulk area never starts at offset 0 (k_str_copy may read 15 bytes before a dictionary)
+    uint64_t io = 0, bo = index_total;
+    for (int c = 0; counts && c < SL_COUNT; c++) counts[c] = 0;
+    for (int i = 0; i < n; i++) {
+        DevPack p;
+        p.in_off = d[i].in_off; p.out_off = d[i].out_off; p.pack_size = d[i].pack_size; p.data_size = d[i].data_size;
+        p.obj_count = d[i].obj_count; p.encode_type = d[i].encode_type; p.data_type = d[i].data_type;
+        p.width = (d[i].data_type == 1 || d[i].data_type == 3) ? 32 : (d[i].data_type == 5 ? 0 : 64);
+        p.ds_off = 0;
+        const ScratchNeed need = pack_scratch_layout(p, 0);
+        if (p.encode_type != 0) {
+            p.s_idx[0] += io; p.s_idx[1] += io; p.s_restart += io;
+            p.s_dict += bo; p.s_lens += bo; p.s_rows += bo;
+        }
+        io += need.index;
+        bo += need.bulk;
+        if (packs) packs[i] = p;
+        if (counts) {
+            const int c = p.encode_type == 0 ? SL_RAW : (p.width == 32 ? SL_N32 : (p.width == 64 ? SL_N64 : SL_STR));
+            if (lists) { lists[SL_ALL * kStaticMaxPacks + counts[SL_ALL]] = i; lists[c * kStaticMaxPacks + counts[c]] = i; }
+            counts[SL_ALL]++; counts[c]++;
+        }
+    }
+    return kStaticHeader + bo + 64;
+}
+void launch_static_setup(hipStream_t stream, const StaticBatch& batch, uint8_t* block);
+void launch_export_status(hipStream_t stream, const PackMeta* metas, int count, int32_t* d_status);
+
 // records the calling thread's last error (what ixr_last_error returns) and hands `code` back
 int32_t set_error(int32_t code, const char* message);
 

@@ -18,6 +18,8 @@ ERR_ILLEGAL_ENCODE_TYPE, ERR_UNSUPPORTED_TYPE = -101, -102
 ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_OUT_OF_MEMORY = -1000, -1001, -1002, -1003
 PACK_MAX_ROWS = 65536
 IN_SLACK = 16
+STATIC_MAX_PACKS = 64
+STATIC_SCRATCH_BYTES = 32 << 20
 
 (COL_I_SEQ, COL_I_RAND, COL_I_CAT, COL_I_RUNS, COL_L_TS, COL_L_CARD, COL_L_RAND, COL_F_CARD, COL_D_CARD, COL_S_CAT,
  COL_S_URL, COL_S_UNIQ, COL_S_EMPTY) = range(13)
@@ -111,6 +113,7 @@ _sig = {
     "ixr_plan_kernel_times": (_i32, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(_i32), _i32]),
     "ixr_plan_kernel_bytes": (_i32, [_vp, C.POINTER(_u64), _i32]),
     "ixr_plan_run_dict_structs": (_i32, [_vp, _vp, _u64, _vp, _u64, C.POINTER(_u64), _vp]),
+    "ixr_decode_batch_static": (_i32, [_i32, C.POINTER(PackDesc), _i32, _vp, _u64, _vp, _u64, _vp, _vp]),
     "ixr_decode_pack": (_i32, [_i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32]),
     "ixr_get_dict_struct": (_i32, [_i32, _i32, _i32, _vp, _i32, _vp, _i32]),
     "ixr_get_data_from_dict_struct": (_i32, [_i32, _i32, _i32, _vp, _i32, _vp, _i32]),
