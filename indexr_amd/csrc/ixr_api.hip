@@ -8,6 +8,7 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -193,6 +194,7 @@ struct ixr_plan {
     uint64_t tot_in = 0, tot_out = 0, tot_rows = 0;
     bool profiling = false;
     bool overlap = true;  // numeric kernels on the auxiliary stream beside the string kernels (ixr_plan_set_overlap)
+    bool fused_str = true; // string rows: index and body copy in one kernel (IXR_SPLIT_STR=1: two kernels with per-row offsets in scratch, for A/B runs)
     std::vector<TimedLaunch> timed;       // launches of the last run (profiling only)
     std::vector<hipEvent_t> event_pool;   // reused across runs
     size_t event_used = 0;
@@ -228,6 +230,7 @@ static ixr_plan* plan_create(int32_t device, const ixr_pack_desc* descs, int32_t
     if (scratch_budget == 0) scratch_budget = kDefaultScratchBudget;
     ixr_plan* pl = new ixr_plan();
     pl->device = device;
+    if (const char* e = getenv("IXR_SPLIT_STR")) pl->fused_str = !(e[0] == '1');
     pl->n = n_packs;
     pl->descs.assign(descs, descs + n_packs);
     pl->hpacks.resize(n_packs);
@@ -425,8 +428,13 @@ extern "C" int32_t ixr_plan_run(ixr_plan* pl, const void* d_in, uint64_t in_byte
         TN.run("k_dict_num<u64>", g.cnt[L_N64], [&] { launch_dict_num(cn, L + g.off[L_N64], g.cnt[L_N64], 64); });
         TN.run("k_copy_raw", g.cnt[L_RAW], [&] { launch_copy_raw(cn, L + g.off[L_RAW], g.cnt[L_RAW]); });
         run_group_front_str(pl, T, c, g, 0);
-        T.run("k_str_index", g.cnt[L_STR], [&] { launch_str_index(c, L + g.off[L_STR], g.cnt[L_STR]); });
-        T.run("k_str_copy", g.cnt[L_STR], [&] { launch_str_copy(c, L + g.off[L_STR], g.cnt[L_STR]); });
+        if (pl->fused_str) {
+            T.run("k_str_index", g.cnt[L_STR], [&] { launch_str_bases(c, L + g.off[L_STR], g.cnt[L_STR]); });
+            T.run("k_str_fused", g.cnt[L_STR], [&] { launch_str_fused(c, L + g.off[L_STR], g.cnt[L_STR]); });
+        } else {
+            T.run("k_str_index", g.cnt[L_STR], [&] { launch_str_index(c, L + g.off[L_STR], g.cnt[L_STR]); });
+            T.run("k_str_copy", g.cnt[L_STR], [&] { launch_str_copy(c, L + g.off[L_STR], g.cnt[L_STR]); });
+        }
         if (fork) {  // the next group reuses this group's scratch: both streams must be done with it
             HIP_TRY(hipEventRecord(pl->ev_join, pl->aux), return IXR_ERR_HIP);
             HIP_TRY(hipStreamWaitEvent(st, pl->ev_join, 0), return IXR_ERR_HIP);
@@ -527,8 +535,8 @@ extern "C" int32_t ixr_decode_batch_static(int32_t device, const ixr_pack_desc* 
     launch_front_combine(c, str, counts[SL_STR], 0);
     launch_front_decode(c, str, counts[SL_STR], 0);
     launch_front_serial(c, str, counts[SL_STR]);
-    launch_str_index(c, str, counts[SL_STR]);
-    launch_str_copy(c, str, counts[SL_STR]);
+    launch_str_bases(c, str, counts[SL_STR]);
+    launch_str_fused(c, str, counts[SL_STR]);
     launch_export_status(st, c.metas, n_packs, d_status);
     HIP_TRY(hipGetLastError(), return IXR_ERR_HIP);
     return 0;
@@ -553,8 +561,12 @@ static void attribute_bytes(ixr_plan* pl, const std::vector<PackMeta>& metas, st
                 const uint64_t index = 4 * (n + 1), body = ds > index ? ds - index : 0;
                 if (m.entries_plain) by["k_str_dict_scan"] += m.ids_off;
                 else { by["k_delta<u32>(str lens)"] += m.sfx_off; by[m.front_blocks ? "k_front_decode" : "k_front_serial"] += m.sfx_len; }
-                by["k_str_index"] += (ps - m.ids_off) + index;
-                by["k_str_copy"] += body;
+                if (pl->fused_str) {
+                    by["k_str_fused"] += (ps - m.ids_off) + index + body;  // id stream in; row index and body out
+                } else {
+                    by["k_str_index"] += (ps - m.ids_off) + index;
+                    by["k_str_copy"] += body;
+                }
                 break;
             }
             case K_DELTA_STR: {

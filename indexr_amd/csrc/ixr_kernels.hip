@@ -79,6 +79,9 @@ __device__ __forceinline__ uint32_t bit_width32(uint32_t v) { return v ? 32u - (
 #ifndef IXR_FRONT_BATCH
 #define IXR_FRONT_BATCH 8
 #endif
+#ifndef IXR_FUSED_CHUNKS
+#define IXR_FUSED_CHUNKS 4      // 16-byte chunks per lane and step of k_str_fused
+#endif
 constexpr int kParseLaneThreshold = 16384;  // packs per launch from which k_parse_lanes is used
 constexpr uint32_t kWin = 4096;
 constexpr uint32_t kSegTab = 128;                      // short-segment table of the RLE tile expansion (uint2 entries)
@@ -717,7 +720,7 @@ __global__ __launch_bounds__(256) void k_delta(const DevPack* __restrict__ packs
     const PackMeta& M = metas[pi];
     if (M.status < 0) return;
     const int kind = M.kind;
-    if (dict_only && kind == K_DELTA_NUM) return;  // its rows would go to the output arena, which does not exist in this mode
+    if ((dict_only & 1) && kind == K_DELTA_NUM) return;  // its rows would go to the output arena, which does not exist in this mode
     const uint8_t* base = in + P.in_off;
     const int tid = threadIdx.x;
 
@@ -1152,7 +1155,7 @@ __global__ __launch_bounds__(256) void k_str_dict_scan(const DevPack* __restrict
     const int pi = list[blockIdx.x];
     PackMeta& M = metas[pi];
     if (M.status < 0 || (M.kind != K_DICT_STR && M.kind != K_DELTA_STR)) return;
-    if (dict_only && M.kind == K_DELTA_STR) return;  // a front-coded pack's "dictionary" is its output
+    if ((dict_only & 1) && M.kind == K_DELTA_STR) return;  // a front-coded pack's "dictionary" is its output
     const DevPack P = packs[pi];
     const uint8_t* base = in + P.in_off;
     const uint32_t ec = M.entry_count;
@@ -1285,7 +1288,7 @@ __global__ __launch_bounds__(64) void k_front_serial(const DevPack* __restrict__
                                                      uint8_t* __restrict__ out, uint8_t* __restrict__ scratch, int dict_only) {
     const int pi = list[blockIdx.y];
     const DevPack P = packs[pi];
-    if (dict_only && metas[pi].kind == K_DELTA_STR) return;
+    if ((dict_only & 1) && metas[pi].kind == K_DELTA_STR) return;
     FrontCtx f;
     if (!front_ctx(f, P, metas[pi], in, out, scratch, scratch, 0, false)) return;
     const uint32_t max_len = metas[pi].max_len;
@@ -1559,7 +1562,7 @@ __global__ __launch_bounds__(256) void k_row_scan(const DevPack* __restrict__ pa
 // StringsStruct.Builder, StringsStruct.java:120-158) and each row's slice start into scratch, checks that the body fits,
 // zero-fills what the body leaves of dpn.dataSize.  (DictStruct.decodeStrings, DictStruct.java:97-110.)
 // ---------------------------------------------------------------------------------------------------------------
-template <int kWaves>
+template <int kWaves, bool kBasesOnly>
 __global__ __launch_bounds__(kWaves * 64) void k_str_index(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                     PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ scratch) {
@@ -1645,6 +1648,10 @@ __global__ __launch_bounds__(kWaves * 64) void k_str_index(const DevPack* __rest
             total += v;
         }
         const uint32_t o0 = carry + before;
+        if constexpr (kBasesOnly) {
+            // k_str_fused redoes the per-row work where the rows are copied: all it needs from here is where the tile starts
+            if (lane == 0 && cnt) srcoff[tile] = o0;
+        } else
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const uint32_t r = q * 256 + 4 * lane;
@@ -1785,6 +1792,171 @@ __global__ __launch_bounds__(256) void k_str_copy(const DevPack* __restrict__ pa
         const uint4 wB = ld16u(dbody16 + (uint32_t)(s_dlt[rB] + (hasB ? cB : cA)));
         finish(cA, fA, eA, rA, wA);
         if (hasB) finish(cB, fB, eB, rB, wB);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_str_fused: row index and body copy of string dictionary packs in one kernel, one WAVE per tile of kRleTile rows; no
+// workgroup barrier anywhere.  The wave expands its tile's ids, looks the rows' dictionary slices up, scans the row lengths
+// (the tile's first offset comes from k_str_index<.., true>, which leaves one word per tile instead of eight bytes per
+// row), writes the tile's part of the output index and keeps the rows' offsets in LDS; then it produces the tile's stretch
+// of the body in 16-byte aligned chunks exactly as k_str_copy does (row of the chunk's first byte by binary search in
+// LDS, one unaligned 16-byte load per row that overlaps the chunk, merged under byte masks, full-width streaming stores).
+// Nothing about the rows is read back from memory: what a copy kernel gets from HBM at the head of its dependency chain
+// is what it waits for, and per-row offsets are 8 bytes for every ~55 the body holds.
+// (DictStruct.decodeStrings, DictStruct.java:97-110; StringsStruct.Builder, StringsStruct.java:120-158.)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kFusedWaveLds = 8224;  // per wave: stream window + id tile while expanding (7184), then offsets[1025] + deltas[1024]
+static_assert(kFusedWaveLds >= kWinAlloc + 2 * kRleTile && kFusedWaveLds >= 4 * (2 * kRleTile + 1) + 16 && kFusedWaveLds % 16 == 0, "LDS layout");
+
+__global__ __launch_bounds__(256) void k_str_fused(const DevPack* __restrict__ packs, const int* __restrict__ list,
+                                                   const PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
+                                                   uint8_t* __restrict__ out, const uint8_t* __restrict__ scratch) {
+    __shared__ __align__(16) uint8_t smem[4][kFusedWaveLds];
+    uint32_t bx, by;
+    pack_block_remap(bx, by);
+    const int pi = list[by];
+    const PackMeta& M = metas[pi];
+    if (M.status < 0 || M.kind != K_DICT_STR) return;
+    const DevPack& P = packs[pi];
+    const uint32_t n = (uint32_t)P.obj_count, ec = M.entry_count;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t tile = bx * 4 + wave;
+    const uint32_t tile_start = tile * (uint32_t)kRleTile;
+    if (tile_start >= n) return;
+    const uint32_t tile_end = min(n, tile_start + (uint32_t)kRleTile), cnt = tile_end - tile_start;
+    const uint32_t* __restrict__ doff = (const uint32_t*)(scratch + P.s_dict);
+    const uint8_t* dbody = scratch + P.s_dict + 4ull * (ec + 1);
+    uint32_t* __restrict__ off = (uint32_t*)(out + P.out_off);
+    uint8_t* body = out + P.out_off + 4ull * (n + 1);
+    // shift all body positions by A so that position 0 is 16-byte aligned in memory
+    const uint32_t A = (uint32_t)((uintptr_t)body & 15);
+    uint8_t* base16 = body - A;
+    const uint32_t tbase = ((const uint32_t*)(scratch + P.s_rows))[tile];  // offset of the tile's first row
+    uint8_t* wl = smem[wave];
+
+    // ---- the tile's ids, the rows' dictionary slices, the scan of their lengths
+    uint2 ab[16];
+    {
+        uint16_t* ids = (uint16_t*)(wl + kWinAlloc);
+        Win w;
+        w.init(in + P.in_off, (uint32_t)P.pack_size, wl);
+        rle_tile_expand(w, M.id_bw, M.ids_off + 4 + M.ids_len, ((const uint4*)(scratch + P.s_restart))[tile], tile_start, tile_end, ids);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t r = q * 256 + 4 * lane;
+            const uint2 four = ((const uint2*)ids)[q * 64 + lane];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                uint32_t id = ((g < 2 ? four.x : four.y) >> (16 * (g & 1))) & 0xFFFFu;
+                if (r + g >= cnt || id >= ec) id = 0;  // ids were checked by the index kernel
+                __builtin_memcpy(&ab[q * 4 + g], doff + id, 8);  // doff[id], doff[id + 1]
+            }
+        }
+        Win::wave_lds_sync();  // the id tile and the window are dead: their memory becomes the offset tables
+    }
+    uint32_t* s_off = (uint32_t*)wl;                    // [cnt + 1] shifted output offsets of the tile's rows
+    uint32_t* s_dlt = (uint32_t*)(wl + 4 * (kRleTile + 1) + 12);  // [cnt] srcOff - s_off + 16 (mod 2^32), 16-byte aligned
+    {
+        uint32_t run = tbase + A;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t r = q * 256 + 4 * lane;
+            uint32_t len[4], ex[4], s4 = 0;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                len[g] = r + g < cnt ? ab[q * 4 + g].y - ab[q * 4 + g].x : 0u;
+                ex[g] = s4;
+                s4 += len[g];
+            }
+            const uint32_t inc = wave_incl_scan(s4);
+            const uint32_t first = run + inc - s4;
+#pragma unroll
+            for (int g = 0; g < 4; g++) ex[g] += first;
+            run += __builtin_amdgcn_readlane(inc, 63);
+            // the output index (unshifted) leaves as 16-byte stores; the shifted offsets and the source deltas go to LDS
+            if (r + 3 < cnt) {
+                *(uint4*)(off + tile_start + r) = make_uint4(ex[0] - A, ex[1] - A, ex[2] - A, ex[3] - A);
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    if (r + g < cnt) off[tile_start + r + g] = ex[g] - A;
+            }
+            if (r < cnt) {  // rows past the tile's end have length 0: their entries equal the tile's end offset
+                *(uint4*)(s_off + r) = make_uint4(ex[0], ex[1], ex[2], ex[3]);
+                *(uint4*)(s_dlt + r) = make_uint4(ab[q * 4].x - ex[0] + 16u, ab[q * 4 + 1].x - ex[1] + 16u, ab[q * 4 + 2].x - ex[2] + 16u,
+                                                  ab[q * 4 + 3].x - ex[3] + 16u);
+            }
+        }
+        if (lane == 0) s_off[cnt] = run;
+        Win::wave_lds_sync();
+    }
+    const uint32_t rows = cnt;
+    const uint32_t b0 = s_off[0], b1 = s_off[rows];
+    if (b1 <= b0) return;
+    const uint8_t* dbody16 = dbody - 16;  // chunk byte k of row r comes from dbody16[s_dlt[r] + cpos + k]; the sum is >= 1
+
+    // One 16-byte chunk: finish it given the row `r` of its first byte; handles chunks that straddle rows.
+    auto finish = [&](uint32_t cpos, uint32_t first, uint32_t cend, uint32_t r, uint4 w) {
+        uint32_t rend = s_off[r + 1];
+        uint32_t pos = min(cend, rend);
+        if (pos < cend) {
+            uint64_t wlo = (uint64_t)w.x | ((uint64_t)w.y << 32), whi = (uint64_t)w.z | ((uint64_t)w.w << 32);
+            while (pos < cend) {
+                do { r++; rend = s_off[r + 1]; } while (rend <= pos && r + 1 < rows);  // next row that is not empty
+                const uint32_t segend = min(cend, max(rend, pos + 1));
+                const uint4 v = ld16u(dbody16 + (uint32_t)(s_dlt[r] + cpos));
+                const int a = (int)(pos - cpos), e = (int)(segend - cpos);
+                const uint64_t ml = low_bytes(e) & ~low_bytes(a), mh = low_bytes(e - 8) & ~low_bytes(a - 8);
+                wlo = (wlo & ~ml) | (((uint64_t)v.x | ((uint64_t)v.y << 32)) & ml);
+                whi = (whi & ~mh) | (((uint64_t)v.z | ((uint64_t)v.w << 32)) & mh);
+                pos = segend;
+            }
+            w = make_uint4((uint32_t)wlo, (uint32_t)(wlo >> 32), (uint32_t)whi, (uint32_t)(whi >> 32));
+        }
+        if (first == cpos && cend == cpos + 16u) {
+            st16_stream(base16 + cpos, w);
+        } else {  // the tile's first and last chunk are shared with the neighbouring tiles
+            const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t q = cpos + k;
+                if (q >= first && q < cend) base16[q] = (uint8_t)(wv[k >> 2] >> (8 * (k & 3)));
+            }
+        }
+    };
+
+    // kFusedChunks chunks per lane and step (1 KiB apart, so that each store instruction of the wave stays contiguous): the
+    // row searches run in one branch-free loop and all first loads are in flight together.
+    constexpr int U = IXR_FUSED_CHUNKS;
+    for (uint32_t c0 = (b0 & ~15u) + 16u * lane; c0 < b1; c0 += U * 16u * 64u) {
+        uint32_t cp[U], fp[U], ep[U], rr[U];
+        bool has[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            cp[u] = c0 + u * 16u * 64u;
+            has[u] = cp[u] < b1;
+            if (!has[u]) cp[u] = c0;  // lanes past the end repeat their first chunk's search and load, and store nothing
+            fp[u] = max(cp[u], b0);
+            ep[u] = min(cp[u] + 16u, b1);
+            rr[u] = 0;
+        }
+        // largest r in [0, rows) with s_off[r] <= first: s_off[0] = b0 <= first < b1 = s_off[rows]
+#pragma unroll
+        for (uint32_t step = kRleTile / 2; step >= 1; step >>= 1) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t c = rr[u] + step;
+                const uint32_t o = s_off[min(c, rows)];
+                if (c < rows && o <= fp[u]) rr[u] = c;
+            }
+        }
+        uint4 w[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) w[u] = ld16u(dbody16 + (uint32_t)(s_dlt[rr[u]] + cp[u]));
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (has[u]) finish(cp[u], fp[u], ep[u], rr[u], w[u]);
     }
 }
 
@@ -2602,8 +2774,17 @@ void launch_str_index(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;
     // few packs: 16 waves each shorten the one pack's chain of rounds; many packs: workgroups of 4 waves, which find room on
     // a compute unit beside the numeric kernels of the other stream
-    if (count < 1024) hipLaunchKernelGGL(k_str_index<16>, dim3(count), dim3(1024), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
-    else hipLaunchKernelGGL(k_str_index<4>, dim3(count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+    if (count < 1024) hipLaunchKernelGGL((k_str_index<16, false>), dim3(count), dim3(1024), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+    else hipLaunchKernelGGL((k_str_index<4, false>), dim3(count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+}
+void launch_str_bases(const LaunchCtx& c, const int* list, int count) {
+    if (count <= 0) return;
+    if (count < 1024) hipLaunchKernelGGL((k_str_index<16, true>), dim3(count), dim3(1024), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+    else hipLaunchKernelGGL((k_str_index<4, true>), dim3(count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+}
+void launch_str_fused(const LaunchCtx& c, const int* list, int count) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_str_fused, dim3(IXR_PACK_TILES / 4, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
 }
 void launch_row_scan(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;

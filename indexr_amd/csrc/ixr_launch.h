@@ -89,6 +89,8 @@ void launch_front_decode(const LaunchCtx& c, const int* list, int count, int use
 void launch_row_scan(const LaunchCtx& c, const int* list, int count);
 void launch_str_index(const LaunchCtx& c, const int* list, int count);
 void launch_str_copy(const LaunchCtx& c, const int* list, int count);
+void launch_str_bases(const LaunchCtx& c, const int* list, int count);  // k_str_index that leaves one offset per 1024-row tile
+void launch_str_fused(const LaunchCtx& c, const int* list, int count);  // row index + body copy, one wave per tile
 void launch_ds_meta(const LaunchCtx& c, const int* list, int count);
 void launch_ds_rows(const LaunchCtx& c, const int* list, int count, int mode);  // 0: 32 bit, 1: 64 bit, 2: strings
 void launch_checksum(const LaunchCtx& c, int count, unsigned long long* sums);  // all packs of the plan
