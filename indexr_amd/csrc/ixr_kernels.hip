@@ -88,6 +88,26 @@ constexpr uint32_t kSegTab = 128;                      // short-segment table of
 constexpr uint32_t kWinAlloc = kWin + 16 + 8 * kSegTab;  // bytes of LDS per window: data, 16 spare bytes so that 12-byte peeks
                                                         // never run off, and the segment table
 
+// A wave-uniform 64-bit value, known to the compiler as such (kept in scalar registers).
+__device__ __forceinline__ uint64_t uniform64(uint64_t a) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) << 32) |
+           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a);
+}
+// Loads *p, where p is the same in every lane, through the scalar cache (constant address space + uniform address).
+// Only for memory that no kernel writes while this one runs.
+template <class T>
+__device__ __forceinline__ T uniform_load(const T* p) {
+    typedef const T __attribute__((address_space(4))) * kp;
+    return *(kp)uniform64((uint64_t)p);
+}
+template <>
+__device__ __forceinline__ uint4 uniform_load<uint4>(const uint4* p) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef const u32x4 __attribute__((address_space(4))) * kp;
+    const u32x4 v = *(kp)uniform64((uint64_t)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 struct Win {
     const uint8_t* base;  // pack start in global memory, 16-byte aligned
     uint32_t limit16;     // bytes readable from `base` in whole 16-byte chunks (pack + arena slack, rounded down)
@@ -97,10 +117,11 @@ struct Win {
     __device__ __forceinline__ void init(const uint8_t* b, uint32_t pack_size, uint8_t* l) {
         base = b; limit16 = __builtin_amdgcn_readfirstlane((pack_size + kInSlack) & ~15u); lds = l; w0 = 0xFFFFFFFFu;
     }
-    // LDS instructions of one wave execute in program order, so a wavefront-scope fence (no wait on outstanding global
-    // stores or loads) plus a scheduling barrier is all that ordering window writes against window reads needs.
+    // LDS instructions of one wave execute in program order, so ordering window writes against window reads needs a
+    // fence for the compiler only, and only over LDS (a fence that covers global memory as well can make the wave wait
+    // for the stores it has in flight).
     static __device__ __forceinline__ void wave_lds_sync() {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
     }
     __device__ __forceinline__ void load(uint32_t pos) {
@@ -1832,7 +1853,7 @@ __global__ __launch_bounds__(256) void k_str_fused(const DevPack* __restrict__ p
     // shift all body positions by A so that position 0 is 16-byte aligned in memory
     const uint32_t A = (uint32_t)((uintptr_t)body & 15);
     uint8_t* base16 = body - A;
-    const uint32_t tbase = ((const uint32_t*)(scratch + P.s_rows))[tile];  // offset of the tile's first row
+    const uint32_t tbase = uniform_load((const uint32_t*)(scratch + P.s_rows) + tile);  // offset of the tile's first row
     uint8_t* wl = smem[wave];
 
     // ---- the tile's ids, the rows' dictionary slices, the scan of their lengths
@@ -1841,7 +1862,8 @@ __global__ __launch_bounds__(256) void k_str_fused(const DevPack* __restrict__ p
         uint16_t* ids = (uint16_t*)(wl + kWinAlloc);
         Win w;
         w.init(in + P.in_off, (uint32_t)P.pack_size, wl);
-        rle_tile_expand(w, M.id_bw, M.ids_off + 4 + M.ids_len, ((const uint4*)(scratch + P.s_restart))[tile], tile_start, tile_end, ids);
+        rle_tile_expand(w, M.id_bw, M.ids_off + 4 + M.ids_len, uniform_load((const uint4*)(scratch + P.s_restart) + tile), tile_start,
+                        tile_end, ids);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const uint32_t r = q * 256 + 4 * lane;

@@ -77,6 +77,12 @@ def main():
         ms, alg = t.get("k_str_fused") or t["k_str_copy"]
         print("%-46s k_str_copy %.3f ms  %.0f GB/s body  | str_index %.3f front_decode %.3f | dict %d B" % (
             name, ms, alg / ms / 1e6, t["k_str_index"][0], t.get("k_front_decode", (0, 0))[0], sum(len(e) for e in ent)), flush=True)
+        if hasattr(L.lib, "ixr_debug_phases"):  # build with IXR_DEFS=-DIXR_PHASES: cycles per phase, summed over waves
+            import ctypes
+            ph = (ctypes.c_ulonglong * 16)()
+            L.lib.ixr_debug_phases(ph)
+            waves = 4 * 64 * args.packs  # 4 runs
+            print("   phases, cycles per wave:", " ".join("%d" % (v / waves) for v in ph[:12]), flush=True)
         plan.destroy(); d_in.free(); d_out.free()
 
 

@@ -39,6 +39,23 @@ __global__ __launch_bounds__(256) void k(const uint8_t* __restrict__ src, const 
             else if (MODE == 12) p = (rowpos[(g / 12) % rp_len] + (uint32_t)(g % 12) * 16) % (src_bytes - 64);   // one streamed index word per 192 bytes
             else if (MODE == 13) p = (rowpos[(g / 48) % rp_len] + (uint32_t)(g % 48) * 16) % (src_bytes - 64);   // per 768 bytes
             else if (MODE == 14) p = (rowpos[(g / 192) % rp_len] + (uint32_t)(g % 192) * 16) % (src_bytes - 64); // per 3 KB
+            else if (MODE == 15) {
+                // the wave's 64 chunks (pieces g0 .. g0+63) read index words (g0/3) .. (g0+63)/3: a wave-uniform base, fetched
+                // with scalar loads (the scalar cache's own path to L2), then picked per lane
+                const size_t g0 = (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)((g - (threadIdx.x & 63)) & 0xFFFFFFFFu)) + ((g - (threadIdx.x & 63)) & ~0xFFFFFFFFull);
+                const size_t w0 = (g0 / 3) % (rp_len - 24);
+                typedef const uint32_t __attribute__((address_space(4))) * kptr;  // constant address space: uniform loads go to the scalar cache
+                const uint64_t ba = (uint64_t)(rowpos + w0);
+                const kptr base = (kptr)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ba >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ba));
+                uint32_t t[24];
+#pragma unroll
+                for (int q = 0; q < 24; q++) t[q] = base[q];
+                const uint32_t sel = (uint32_t)(g / 3 - g0 / 3);  // 0..21
+                uint32_t x = t[0];
+#pragma unroll
+                for (int q = 1; q < 24; q++) x = sel == (uint32_t)q ? t[q] : x;
+                p = x + (uint32_t)(g % 3) * 16;
+            }
             else if (MODE == 8) p = (rowpos[(g / 3) % rp_len] ^ rowpos[(g / 3 + 1) % rp_len]) % (src_bytes - 64);   // two streamed index words per piece
             else if (MODE == 7 || MODE == 9) {
                 // an 8-step search over 257 offsets in LDS, then the index word of the row it finds
@@ -79,7 +96,7 @@ int main(int argc, char** argv) {
     auto timeit = [&](const char* name, auto fn) {
         fn(); hipDeviceSynchronize();
         float best = 1e9;
-        for (int it = 0; it < 5; it++) { hipEventRecord(e0); fn(); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms; }
+        for (int it = 0; it < 5; it++) { hipEventRecord(e0); fn(); hipError_t le = hipGetLastError(); hipEventRecord(e1); hipError_t se = hipEventSynchronize(e1); if (le != hipSuccess || se != hipSuccess) { printf("%s: launch %s, sync %s\n", name, hipGetErrorString(le), hipGetErrorString(se)); exit(1); } float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms; }
         printf("%-58s %8.3f ms  %8.1f GB/s of pieces\n", name, best, nblocks * vpb * 16 / 1e9 / (best / 1e3));
     };
 #define RUN(M, NT, name) timeit(name, [&] { hipLaunchKernelGGL((k<M, NT>), dim3(nblocks), dim3(256), 0, 0, src, drp, a, vpb, src_bytes, rp.size() - 8); })
@@ -97,6 +114,8 @@ int main(int argc, char** argv) {
     timeit("  same, index loads non-temporal", [&] { hipLaunchKernelGGL((k<10, true, 4>), dim3(nblocks), dim3(256), 0, 0, src, drp, a, vpb, src_bytes, rp.size() - 8); });
     timeit("  same, index nt + plain stores", [&] { hipLaunchKernelGGL((k<10, false, 4>), dim3(nblocks), dim3(256), 0, 0, src, drp, a, vpb, src_bytes, rp.size() - 8); });
     timeit("  index streamed, NO gather (index value stored)", [&] { hipLaunchKernelGGL((k<11, true, 4>), dim3(nblocks), dim3(256), 0, 0, src, drp, a, vpb, src_bytes, rp.size() - 8); });
+    RUNU(15, 4, "  index streamed through the SCALAR cache (s_load), 4 pieces");
+    RUNU(15, 1, "  same, 1 piece");
     RUNU(12, 4, "  one streamed index word per 192 bytes of output");
     RUNU(13, 4, "  one streamed index word per 768 bytes of output");
     RUNU(14, 4, "  one streamed index word per 3 KB of output");
