@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <cstring>
 #include <map>
 #include <string>
@@ -488,17 +489,11 @@ extern "C" int32_t ixr_plan_run_dict_structs(ixr_plan* pl, const void* d_in, uin
 static_assert(sizeof(SmallDesc) == sizeof(ixr_pack_desc), "device and ABI descriptor layouts must match");
 static_assert(IXR_STATIC_MAX_PACKS == kStaticMaxPacks, "device code and the C ABI must agree on the batch limit");
 
-extern "C" int32_t ixr_decode_batch_static(int32_t device, const ixr_pack_desc* descs, int32_t n_packs, const void* d_in,
-                                           uint64_t in_bytes, void* d_out, uint64_t out_bytes, int32_t* d_status, void* stream) {
-    if (!descs || !d_in || !d_out || !d_status) return fail(IXR_ERR_INVALID_ARGUMENT, "null argument");
-    if (n_packs < 1 || n_packs > IXR_STATIC_MAX_PACKS)
-        return fail(IXR_ERR_INVALID_ARGUMENT, "%d packs: this entry point takes 1..%d packs per call (use a plan for more)", n_packs, IXR_STATIC_MAX_PACKS);
-    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15) || ((uintptr_t)d_status & 3)) return fail(IXR_ERR_INVALID_ARGUMENT, "misaligned device pointer");
-    int32_t rc = ixr_init(device);
-    if (rc) return rc;
-    if (device >= 64) return fail(IXR_ERR_INVALID_ARGUMENT, "device %d: the static scratch is kept for devices 0..63", device);
-    uint8_t* block = g_static_ptr[device].load(std::memory_order_acquire);
-    if (!block) return fail(IXR_ERR_BUG, "static scratch of device %d was not resolved", device);
+// Decodes 1..IXR_STATIC_MAX_PACKS packs with every working array inside `block` (IXR_STATIC_SCRATCH_BYTES of device memory
+// laid out by static_layout).  Launches only: nothing is allocated, nothing is waited for.  `too_big`, when given, is set
+// instead of failing when the batch needs more working memory than the block holds.
+static int32_t decode_small(const ixr_pack_desc* descs, int32_t n_packs, const void* d_in, uint64_t in_bytes, void* d_out,
+                            uint64_t out_bytes, int32_t* d_status, hipStream_t st, uint8_t* block, bool* too_big) {
     StaticBatch batch;
     memset(&batch, 0, sizeof(batch));
     batch.n = n_packs;
@@ -514,10 +509,11 @@ extern "C" int32_t ixr_decode_batch_static(int32_t device, const ixr_pack_desc* 
     }
     int counts[SL_COUNT];
     const uint64_t need = static_layout(batch.d, n_packs, nullptr, nullptr, counts);
-    if (need > IXR_STATIC_SCRATCH_BYTES)
+    if (need > IXR_STATIC_SCRATCH_BYTES) {
+        if (too_big) { *too_big = true; return 0; }
         return fail(IXR_ERR_INVALID_ARGUMENT, "the batch needs %llu bytes of working memory, the static scratch holds %llu: pass fewer packs per call",
                     (unsigned long long)need, (unsigned long long)IXR_STATIC_SCRATCH_BYTES);
-    hipStream_t st = (hipStream_t)stream;
+    }
     launch_static_setup(st, batch, block);
     LaunchCtx c{st, (const DevPack*)block, (PackMeta*)(block + kStaticMetaOff), (const uint8_t*)d_in, (uint8_t*)d_out, block + kStaticHeader};
     const int* lists = (const int*)(block + kStaticListOff);
@@ -540,6 +536,20 @@ extern "C" int32_t ixr_decode_batch_static(int32_t device, const ixr_pack_desc* 
     launch_export_status(st, c.metas, n_packs, d_status);
     HIP_TRY(hipGetLastError(), return IXR_ERR_HIP);
     return 0;
+}
+
+extern "C" int32_t ixr_decode_batch_static(int32_t device, const ixr_pack_desc* descs, int32_t n_packs, const void* d_in,
+                                           uint64_t in_bytes, void* d_out, uint64_t out_bytes, int32_t* d_status, void* stream) {
+    if (!descs || !d_in || !d_out || !d_status) return fail(IXR_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_packs < 1 || n_packs > IXR_STATIC_MAX_PACKS)
+        return fail(IXR_ERR_INVALID_ARGUMENT, "%d packs: this entry point takes 1..%d packs per call (use a plan for more)", n_packs, IXR_STATIC_MAX_PACKS);
+    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15) || ((uintptr_t)d_status & 3)) return fail(IXR_ERR_INVALID_ARGUMENT, "misaligned device pointer");
+    int32_t rc = ixr_init(device);
+    if (rc) return rc;
+    if (device >= 64) return fail(IXR_ERR_INVALID_ARGUMENT, "device %d: the static scratch is kept for devices 0..63", device);
+    uint8_t* block = g_static_ptr[device].load(std::memory_order_acquire);
+    if (!block) return fail(IXR_ERR_BUG, "static scratch of device %d was not resolved", device);
+    return decode_small(descs, n_packs, d_in, in_bytes, d_out, out_bytes, d_status, (hipStream_t)stream, block, nullptr);
 }
 
 // Attribution of a pack's algorithmic bytes (packSize + dataSize) to the kernels that consume / produce them.
@@ -666,7 +676,122 @@ struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
     bool alloc(uint64_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess; }
 };
+
+// Everything one ixr_decode_pack call needs on a device, allocated once and handed from call to call: a stream, device
+// input / output buffers, a working block laid out like the static scratch, pinned staging on the host.  A call takes a
+// context from the device's pool and puts it back, so there are as many contexts as calls that ever overlapped.  The
+// pool lives until the process ends (the HIP runtime may be gone by the time static destructors run).
+struct PackCtx {
+    hipStream_t stream = nullptr;
+    uint8_t* d_in = nullptr;
+    uint8_t* d_out = nullptr;
+    uint8_t* d_block = nullptr;
+    int32_t* d_status = nullptr;
+    uint8_t* h_in = nullptr;   // pinned
+    uint8_t* h_out = nullptr;  // pinned
+    int32_t* h_status = nullptr;
+    uint64_t in_cap = 0, out_cap = 0;
+
+    bool reserve(uint64_t in_bytes, uint64_t out_bytes) {
+        if (!stream && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
+        if (!d_block && hipMalloc((void**)&d_block, IXR_STATIC_SCRATCH_BYTES) != hipSuccess) return false;
+        if (!d_status && hipMalloc((void**)&d_status, 64) != hipSuccess) return false;
+        if (!h_status && hipHostMalloc((void**)&h_status, 64, hipHostMallocDefault) != hipSuccess) return false;
+        if (in_bytes > in_cap) {
+            const uint64_t cap = std::max<uint64_t>(in_bytes, 1ull << 20);
+            if (d_in) (void)hipFree(d_in);
+            if (h_in) (void)hipHostFree(h_in);
+            d_in = nullptr; h_in = nullptr; in_cap = 0;
+            if (hipMalloc((void**)&d_in, cap) != hipSuccess || hipHostMalloc((void**)&h_in, cap, hipHostMallocDefault) != hipSuccess) return false;
+            in_cap = cap;
+        }
+        if (out_bytes > out_cap) {
+            const uint64_t cap = std::max<uint64_t>(out_bytes, 1ull << 20);
+            if (d_out) (void)hipFree(d_out);
+            if (h_out) (void)hipHostFree(h_out);
+            d_out = nullptr; h_out = nullptr; out_cap = 0;
+            if (hipMalloc((void**)&d_out, cap) != hipSuccess || hipHostMalloc((void**)&h_out, cap, hipHostMallocDefault) != hipSuccess) return false;
+            out_cap = cap;
+        }
+        return true;
+    }
+};
+struct PackCtxPool {
+    std::mutex mu;
+    std::vector<PackCtx*> idle[64];
+};
+PackCtxPool& pack_ctx_pool() {
+    static PackCtxPool* pool = new PackCtxPool();  // never destroyed, see above
+    return *pool;
+}
+struct PackCtxLease {
+    int device;
+    PackCtx* ctx;
+    explicit PackCtxLease(int dev) : device(dev), ctx(nullptr) {
+        PackCtxPool& pool = pack_ctx_pool();
+        {
+            std::lock_guard<std::mutex> g(pool.mu);
+            if (!pool.idle[dev].empty()) { ctx = pool.idle[dev].back(); pool.idle[dev].pop_back(); }
+        }
+        if (!ctx) ctx = new PackCtx();
+    }
+    ~PackCtxLease() {
+        PackCtxPool& pool = pack_ctx_pool();
+        std::lock_guard<std::mutex> g(pool.mu);
+        pool.idle[device].push_back(ctx);
+    }
+};
 }  // namespace
+
+// Rows of one pack through a pooled context: one copy in, the small-batch kernels, status and rows out, one wait.
+// Returns 1 when the pack needs more working memory than a context holds (the caller then takes the plan path).
+static int32_t single_pack_pooled(int32_t device, const ixr_pack_desc& d, const void* in, void* out, int32_t* rc_out) {
+    if (device < 0 || device >= 64) return 1;
+    int32_t rc = ixr_init(device);
+    if (rc) { *rc_out = rc; return 0; }
+    const uint64_t in_bytes = align16((uint64_t)d.pack_size) + IXR_IN_SLACK;
+    const uint64_t out_bytes = align16((uint64_t)std::max(d.data_size, 16)) + 16;
+    PackCtxLease lease(device);
+    PackCtx& x = *lease.ctx;
+    if (hipSetDevice(device) != hipSuccess || !x.reserve(in_bytes, out_bytes)) {
+        *rc_out = fail(IXR_ERR_OUT_OF_MEMORY, "device or pinned memory for a single-pack context could not be allocated");
+        return 0;
+    }
+    memcpy(x.h_in, in, (size_t)d.pack_size);
+    memset(x.h_in + d.pack_size, 0, (size_t)(in_bytes - (uint64_t)d.pack_size));
+    bool too_big = false;
+    hipError_t e = hipMemcpyAsync(x.d_in, x.h_in, in_bytes, hipMemcpyHostToDevice, x.stream);
+    if (e == hipSuccess) {
+        rc = decode_small(&d, 1, x.d_in, in_bytes, x.d_out, out_bytes, x.d_status, x.stream, x.d_block, &too_big);
+        if (rc || too_big) {
+            (void)hipStreamSynchronize(x.stream);
+            if (too_big) return 1;
+            *rc_out = rc;
+            return 0;
+        }
+        e = hipMemcpyAsync(x.h_status, x.d_status, 4, hipMemcpyDeviceToHost, x.stream);
+    }
+    if (e == hipSuccess && d.data_size > 0) e = hipMemcpyAsync(x.h_out, x.d_out, (size_t)d.data_size, hipMemcpyDeviceToHost, x.stream);
+    if (e == hipSuccess) {
+        // a decode is tens of microseconds: poll for it before falling back to a blocking wait, whose wake-up alone can
+        // take several times as long
+        for (int spin = 0; spin < 20000 && (e = hipStreamQuery(x.stream)) == hipErrorNotReady; spin++) {}
+        if (e == hipErrorNotReady) e = hipStreamSynchronize(x.stream);
+    }
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(x.stream);
+        *rc_out = fail(IXR_ERR_HIP, "single-pack decode failed: %s", hipGetErrorString(e));
+        return 0;
+    }
+    const int32_t status = x.h_status[0];
+    if (status < 0) {
+        *rc_out = fail(status, "decode failed with code %d", status);
+        return 0;
+    }
+    memcpy(out, x.h_out, (size_t)d.data_size);
+    *rc_out = status;
+    return 0;
+}
 
 static int32_t single_pack(int32_t device, int32_t data_type, int32_t encode_type, int32_t obj_count, const void* in,
                            int32_t in_size, void* out, int32_t out_limit, int mode /*0 rows, 1 dict struct, 2 rows from ds*/) {
@@ -700,6 +825,10 @@ static int32_t single_pack(int32_t device, int32_t data_type, int32_t encode_typ
             return fail(IXR_ERR_BUFFER_OVERFLOW, "output too small for the index of %d strings", obj_count);
         }
         dict_cap_override = (uint64_t)in_size;
+    }
+    if (mode == 0 && obj_count <= IXR_PACK_MAX_ROWS) {
+        int32_t rc_fast = 0;
+        if (single_pack_pooled(device, d, in, out, &rc_fast) == 0) return rc_fast;
     }
     ixr_plan* pl = plan_create(device, &d, 1, 0, dict_cap_override);
     if (!pl) return g_code < 0 ? g_code : IXR_ERR_HIP;  // plan_create recorded why (no device, bad descriptor, memory)

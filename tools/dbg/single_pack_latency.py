@@ -1,5 +1,6 @@
 import sys, os, time
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, 'tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from indexr_amd import lib as L
 import oracle_lib as O
