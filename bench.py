@@ -493,32 +493,48 @@ def time_cpu_oracle(np, sample, threads, target_s, log):
 
 
 def time_with_copies(L, np, device, sample, scratch_gib):
-    """H2D of the compressed packs + decode + D2H of the decoded packs, pinned host memory, on the first chunk."""
+    """Compressed packs in pinned host memory -> decoded packs in pinned host memory, on the first chunk of the table:
+    ixr_plan_run_host (copy in, decode and copy out of successive groups overlapped on three streams; the plan is built
+    with a scratch budget that cuts the chunk into about eight groups) beside the plain sequence H2D, decode, D2H."""
     import ctypes as C
     descs, arena = sample
-    plan = L.Plan(device, descs, int(scratch_gib * (1 << 30)))
-    in_bytes, out_bytes = len(arena), plan.out_bytes + 16
-    h_in = L.lib.ixr_host_alloc_pinned(in_bytes)
-    h_out = L.lib.ixr_host_alloc_pinned(out_bytes)
-    C.memmove(h_in, arena.ctypes.data, in_bytes)
-    d_in = L.DeviceBuffer(device, in_bytes)
-    d_out = L.DeviceBuffer(device, out_bytes)
-    best = None
-    for it in range(4):
-        L.lib.ixr_dev_synchronize(device)
-        t = time.perf_counter()
-        L.lib.ixr_memcpy_h2d(device, C.c_void_p(d_in.ptr), C.c_void_p(h_in), in_bytes)
-        plan.run(d_in.ptr, in_bytes, d_out.ptr, out_bytes)
-        L.lib.ixr_memcpy_d2h(device, C.c_void_p(h_out), C.c_void_p(d_out.ptr), out_bytes)
-        dt = time.perf_counter() - t
-        if it and (best is None or dt < best):
-            best = dt
-    status, bad = plan.status()
-    res = {"decoded_GBps": round(plan.total_out / best / 1e9, 2), "rows_per_s": round(plan.total_rows / best, 1), "packs": plan.n,
-           "compressed_GB": round(plan.total_in / 1e9, 3), "decoded_GB": round(plan.total_out / 1e9, 3), "bad_packs": int(bad),
-           "note": "synchronous H2D -> decode -> D2H from/to pinned host memory, no overlap"}
-    plan.destroy(); d_in.free(); d_out.free()
-    L.lib.ixr_host_free_pinned(h_in); L.lib.ixr_host_free_pinned(h_out)
+    in_bytes = len(arena)
+    whole = L.Plan(device, descs, int(scratch_gib * (1 << 30)))
+    out_bytes = whole.out_bytes + 16
+    h_in, h_out = L.PinnedBuffer(in_bytes), L.PinnedBuffer(out_bytes)
+    h_in.array[:] = arena
+    d_in, d_out = L.DeviceBuffer(device, in_bytes), L.DeviceBuffer(device, out_bytes)
+
+    def best_of(fn, runs=4):
+        best = None
+        for it in range(runs):
+            L.lib.ixr_dev_synchronize(device)
+            t = time.perf_counter()
+            fn()
+            dt = time.perf_counter() - t
+            if it and (best is None or dt < best):
+                best = dt
+        return best
+
+    def plain():
+        L.lib.ixr_memcpy_h2d(device, C.c_void_p(d_in.ptr), C.c_void_p(h_in.ptr), in_bytes)
+        whole.run(d_in.ptr, in_bytes, d_out.ptr, out_bytes)
+        L.lib.ixr_memcpy_d2h(device, C.c_void_p(h_out.ptr), C.c_void_p(d_out.ptr), out_bytes)
+
+    t_plain = best_of(plain)
+    _, bad_plain = whole.status()
+    d_in.free(); d_out.free()
+    piped = L.Plan(device, descs, max(whole.scratch_bytes // 8, 64 << 20))
+    t_piped = best_of(lambda: piped.run_host(h_in.ptr, in_bytes, h_out.ptr, out_bytes))
+    _, bad_piped = piped.status()
+    res = {"decoded_GBps": round(whole.total_out / t_piped / 1e9, 2), "rows_per_s": round(whole.total_rows / t_piped, 1), "packs": whole.n,
+           "compressed_GB": round(whole.total_in / 1e9, 3), "decoded_GB": round(whole.total_out / 1e9, 3),
+           "bad_packs": int(bad_piped) + int(bad_plain), "ms": round(t_piped * 1e3, 2),
+           "note": "ixr_plan_run_host: pinned host memory in and out, copies overlapped with the decode group by group",
+           "unoverlapped": {"decoded_GBps": round(whole.total_out / t_plain / 1e9, 2), "ms": round(t_plain * 1e3, 2),
+                            "note": "H2D, ixr_plan_run, D2H one after the other"}}
+    whole.destroy(); piped.destroy()
+    h_in.free(); h_out.free()
     return res
 
 

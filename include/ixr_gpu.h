@@ -128,6 +128,16 @@ int32_t   ixr_plan_kernel_times(ixr_plan* plan, const char** names, float* ms, i
  * to the kernel that produces it, so the entries add up to sum(pack_size) + sum(data_size); traffic to and from scratch
  * memory is not counted. */
 int32_t   ixr_plan_kernel_bytes(ixr_plan* plan, uint64_t* alg_bytes, int32_t cap);
+/* The same decode with both arenas in HOST memory (the descriptors' offsets then are offsets into h_in / h_out): what a
+ * reader pays whose packs are not resident on the device, i.e. the path of StorageColumn.pack -> DataPack.decompress
+ * (indexr-segment/.../storage/StorageColumn.java:78-116) including the trip over PCIe.  The plan's groups (see
+ * scratch_budget_bytes: a smaller budget gives more, smaller groups) go through two device staging buffers per direction:
+ * the copy in of group g+1, the decode of group g and the copy out of group g-1 run at the same time on three streams of
+ * the plan's own.  The call returns when all rows are in h_out; ixr_plan_status(plan, status, NULL) then reports per pack.
+ * Both arenas should be pinned (ixr_host_alloc_pinned): pageable memory works, without the overlap.  The packs must lie
+ * in plan order in the output arena; the (at most 15) alignment bytes between two packs' rows are overwritten with
+ * unspecified values.  The staging buffers, sized for the largest group, stay with the plan until it is destroyed. */
+int32_t   ixr_plan_run_host(ixr_plan* plan, const void* h_in, uint64_t in_bytes, void* h_out, uint64_t out_bytes);
 
 /* ---- batch decode that allocates nothing ----------------------------------------------------------------------------
  * No counterpart in the reference.  For callers that cannot allocate device memory at the point of the call: code under HIP

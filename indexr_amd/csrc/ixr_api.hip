@@ -208,6 +208,14 @@ struct ixr_plan {
     // stream at the start of every group and joins it at the end (events), so the caller still sees one ordered stream.
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // ixr_plan_run_host: per group the byte ranges of the two arenas its packs span, two staging buffers per direction,
+    // three streams (copy in, decode, copy out) and the events that order them; created by the first call
+    struct Span { uint64_t in_lo, in_hi, out_lo, out_hi; };
+    std::vector<Span> spans;
+    uint8_t* h_din[2] = {nullptr, nullptr};
+    uint8_t* h_dout[2] = {nullptr, nullptr};
+    hipStream_t s_h2d = nullptr, s_cmp = nullptr, s_d2h = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_dec[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
 };
 
 extern "C" void ixr_plan_destroy(ixr_plan* plan) {
@@ -221,6 +229,16 @@ extern "C" void ixr_plan_destroy(ixr_plan* plan) {
     if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
     if (plan->ev_join) (void)hipEventDestroy(plan->ev_join);
     if (plan->aux) (void)hipStreamDestroy(plan->aux);
+    for (int b = 0; b < 2; b++) {
+        if (plan->h_din[b]) (void)hipFree(plan->h_din[b]);
+        if (plan->h_dout[b]) (void)hipFree(plan->h_dout[b]);
+        if (plan->ev_in[b]) (void)hipEventDestroy(plan->ev_in[b]);
+        if (plan->ev_dec[b]) (void)hipEventDestroy(plan->ev_dec[b]);
+        if (plan->ev_out[b]) (void)hipEventDestroy(plan->ev_out[b]);
+    }
+    if (plan->s_h2d) (void)hipStreamDestroy(plan->s_h2d);
+    if (plan->s_cmp) (void)hipStreamDestroy(plan->s_cmp);
+    if (plan->s_d2h) (void)hipStreamDestroy(plan->s_d2h);
     delete plan;
 }
 
@@ -403,6 +421,36 @@ void run_group_front_str(ixr_plan* pl, Timer& T, LaunchCtx& c, const Group& g, i
 }
 }  // namespace
 
+// rows of one group: numeric kernels beside the string kernels (two streams), joined at the end
+static int32_t run_group_rows(ixr_plan* pl, Timer& T, Timer& TB, LaunchCtx& c, LaunchCtx& cb, const Group& g) {
+    const int* L = pl->d_lists;
+    hipStream_t st = c.stream;
+    const bool fork = pl->overlap && g.cnt[L_STR] > 0 && (g.cnt[L_N32] + g.cnt[L_N64] + g.cnt[L_RAW]) > 0;
+    LaunchCtx& cn = fork ? cb : c;  // numeric kernels: on the auxiliary stream when there is string work to overlap
+    Timer& TN = fork ? TB : T;
+    if (fork) {
+        HIP_TRY(hipEventRecord(pl->ev_fork, st), return IXR_ERR_HIP);
+        HIP_TRY(hipStreamWaitEvent(pl->aux, pl->ev_fork, 0), return IXR_ERR_HIP);
+    }
+    run_group_front_num(pl, TN, cn, g);
+    TN.run("k_dict_num<u32>", g.cnt[L_N32], [&] { launch_dict_num(cn, L + g.off[L_N32], g.cnt[L_N32], 32); });
+    TN.run("k_dict_num<u64>", g.cnt[L_N64], [&] { launch_dict_num(cn, L + g.off[L_N64], g.cnt[L_N64], 64); });
+    TN.run("k_copy_raw", g.cnt[L_RAW], [&] { launch_copy_raw(cn, L + g.off[L_RAW], g.cnt[L_RAW]); });
+    run_group_front_str(pl, T, c, g, 0);
+    if (pl->fused_str) {
+        T.run("k_str_index", g.cnt[L_STR], [&] { launch_str_bases(c, L + g.off[L_STR], g.cnt[L_STR]); });
+        T.run("k_str_fused", g.cnt[L_STR], [&] { launch_str_fused(c, L + g.off[L_STR], g.cnt[L_STR]); });
+    } else {
+        T.run("k_str_index", g.cnt[L_STR], [&] { launch_str_index(c, L + g.off[L_STR], g.cnt[L_STR]); });
+        T.run("k_str_copy", g.cnt[L_STR], [&] { launch_str_copy(c, L + g.off[L_STR], g.cnt[L_STR]); });
+    }
+    if (fork) {  // the next group reuses this group's scratch: both streams must be done with it
+        HIP_TRY(hipEventRecord(pl->ev_join, pl->aux), return IXR_ERR_HIP);
+        HIP_TRY(hipStreamWaitEvent(st, pl->ev_join, 0), return IXR_ERR_HIP);
+    }
+    return 0;
+}
+
 extern "C" int32_t ixr_plan_run(ixr_plan* pl, const void* d_in, uint64_t in_bytes, void* d_out, uint64_t out_bytes, void* stream) {
     int32_t rc = check_run_args(pl, d_in, in_bytes, d_out, out_bytes);
     if (rc) return rc;
@@ -414,33 +462,100 @@ extern "C" int32_t ixr_plan_run(ixr_plan* pl, const void* d_in, uint64_t in_byte
     LaunchCtx c{st, pl->d_packs, pl->d_metas, (const uint8_t*)d_in, (uint8_t*)d_out, pl->d_scratch};
     LaunchCtx cb = c;
     cb.stream = pl->aux;
-    const int* L = pl->d_lists;
     run_parse_all(pl, T, c);
     for (const Group& g : pl->groups) {
-        const bool fork = pl->overlap && g.cnt[L_STR] > 0 && (g.cnt[L_N32] + g.cnt[L_N64] + g.cnt[L_RAW]) > 0;
-        LaunchCtx& cn = fork ? cb : c;  // numeric kernels: on the auxiliary stream when there is string work to overlap
-        Timer& TN = fork ? TB : T;
-        if (fork) {
-            HIP_TRY(hipEventRecord(pl->ev_fork, st), return IXR_ERR_HIP);
-            HIP_TRY(hipStreamWaitEvent(pl->aux, pl->ev_fork, 0), return IXR_ERR_HIP);
-        }
-        run_group_front_num(pl, TN, cn, g);
-        TN.run("k_dict_num<u32>", g.cnt[L_N32], [&] { launch_dict_num(cn, L + g.off[L_N32], g.cnt[L_N32], 32); });
-        TN.run("k_dict_num<u64>", g.cnt[L_N64], [&] { launch_dict_num(cn, L + g.off[L_N64], g.cnt[L_N64], 64); });
-        TN.run("k_copy_raw", g.cnt[L_RAW], [&] { launch_copy_raw(cn, L + g.off[L_RAW], g.cnt[L_RAW]); });
-        run_group_front_str(pl, T, c, g, 0);
-        if (pl->fused_str) {
-            T.run("k_str_index", g.cnt[L_STR], [&] { launch_str_bases(c, L + g.off[L_STR], g.cnt[L_STR]); });
-            T.run("k_str_fused", g.cnt[L_STR], [&] { launch_str_fused(c, L + g.off[L_STR], g.cnt[L_STR]); });
-        } else {
-            T.run("k_str_index", g.cnt[L_STR], [&] { launch_str_index(c, L + g.off[L_STR], g.cnt[L_STR]); });
-            T.run("k_str_copy", g.cnt[L_STR], [&] { launch_str_copy(c, L + g.off[L_STR], g.cnt[L_STR]); });
-        }
-        if (fork) {  // the next group reuses this group's scratch: both streams must be done with it
-            HIP_TRY(hipEventRecord(pl->ev_join, pl->aux), return IXR_ERR_HIP);
-            HIP_TRY(hipStreamWaitEvent(st, pl->ev_join, 0), return IXR_ERR_HIP);
-        }
+        rc = run_group_rows(pl, T, TB, c, cb, g);
+        if (rc) return rc;
     }
+    HIP_TRY(hipGetLastError(), return IXR_ERR_HIP);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Host arenas in, host arenas out: the plan's groups travel through two staging buffers per direction, so that the
+// copy in of group g+1, the decode of group g and the copy out of group g-1 run at the same time on three streams.
+// (What a reader without device-resident segments pays: IntegratedSegment.column(...).pack(...) loads a pack from
+// storage into host memory first, StorageColumn.java:78-116.)
+// ---------------------------------------------------------------------------------------------------------------
+static int32_t host_pipeline_setup(ixr_plan* pl) {
+    if (!pl->spans.empty()) return 0;
+    std::vector<ixr_plan::Span> spans;
+    uint64_t max_in = 0, max_out = 0;
+    for (const Group& g : pl->groups) {
+        ixr_plan::Span sp{~0ull, 0, ~0ull, 0};
+        for (int k = 0; k < g.cnt[L_ALL]; k++) {
+            const ixr_pack_desc& d = pl->descs[(size_t)pl->group_list_entry(g, L_ALL, k)];
+            sp.in_lo = std::min(sp.in_lo, d.in_off);
+            sp.in_hi = std::max(sp.in_hi, d.in_off + (uint64_t)d.pack_size + IXR_IN_SLACK);
+            sp.out_lo = std::min(sp.out_lo, d.out_off);
+            sp.out_hi = std::max(sp.out_hi, align16(d.out_off + (uint64_t)d.data_size));
+        }
+        // what one group copies out must not cover rows of another group: the packs lie in plan order in the output arena
+        if (!spans.empty() && sp.out_lo < spans.back().out_hi)
+            return fail(IXR_ERR_INVALID_ARGUMENT, "ixr_plan_run_host needs the packs laid out in plan order in the output arena");
+        max_in = std::max(max_in, sp.in_hi - sp.in_lo);
+        max_out = std::max(max_out, sp.out_hi - sp.out_lo);
+        spans.push_back(sp);
+    }
+    hipError_t e = hipSuccess;
+    for (int b = 0; b < 2 && e == hipSuccess; b++) {
+        if ((e = hipMalloc((void**)&pl->h_din[b], align16(max_in) + 16)) != hipSuccess) break;
+        if ((e = hipMalloc((void**)&pl->h_dout[b], align16(max_out) + 16)) != hipSuccess) break;
+        if ((e = hipEventCreateWithFlags(&pl->ev_in[b], hipEventDisableTiming)) != hipSuccess) break;
+        if ((e = hipEventCreateWithFlags(&pl->ev_dec[b], hipEventDisableTiming)) != hipSuccess) break;
+        e = hipEventCreateWithFlags(&pl->ev_out[b], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&pl->s_h2d, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&pl->s_cmp, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&pl->s_d2h, hipStreamNonBlocking);
+    if (e != hipSuccess) return fail(IXR_ERR_OUT_OF_MEMORY, "staging buffers of the host pipeline: %s", hipGetErrorString(e));
+    pl->spans.swap(spans);
+    return 0;
+}
+
+extern "C" int32_t ixr_plan_run_host(ixr_plan* pl, const void* h_in, uint64_t in_bytes, void* h_out, uint64_t out_bytes) {
+    if (!pl) return fail(IXR_ERR_INVALID_ARGUMENT, "null plan");
+    if (!h_in || !h_out) return fail(IXR_ERR_INVALID_ARGUMENT, "null arena");
+    if (in_bytes < pl->in_need) return fail(IXR_ERR_INVALID_ARGUMENT, "input arena too small: %llu < %llu (packs + %d bytes of slack)",
+                                            (unsigned long long)in_bytes, (unsigned long long)pl->in_need, IXR_IN_SLACK);
+    if (out_bytes < pl->out_need) return fail(IXR_ERR_INVALID_ARGUMENT, "output arena too small: %llu < %llu",
+                                              (unsigned long long)out_bytes, (unsigned long long)pl->out_need);
+    HIP_TRY(hipSetDevice(pl->device), return IXR_ERR_HIP);
+    int32_t rc = host_pipeline_setup(pl);
+    if (rc) return rc;
+    if (pl->timed.size() > 200000) { pl->timed.clear(); pl->event_used = 0; }
+    hipStream_t st = pl->s_cmp;
+    Timer T{pl, st}, TB{pl, pl->aux};
+    const uint8_t* hin = (const uint8_t*)h_in;
+    uint8_t* hout = (uint8_t*)h_out;
+    for (size_t gi = 0; gi < pl->groups.size(); gi++) {
+        const Group& g = pl->groups[gi];
+        const ixr_plan::Span& sp = pl->spans[gi];
+        const int b = (int)(gi & 1);
+        const uint64_t out_len = std::min(sp.out_hi, out_bytes) - sp.out_lo;
+        // copy in: the staging buffer is free once the decode two groups back has read it
+        if (gi >= 2) HIP_TRY(hipStreamWaitEvent(pl->s_h2d, pl->ev_dec[b], 0), return IXR_ERR_HIP);
+        HIP_TRY(hipMemcpyAsync(pl->h_din[b], hin + sp.in_lo, sp.in_hi - sp.in_lo, hipMemcpyHostToDevice, pl->s_h2d), return IXR_ERR_HIP);
+        HIP_TRY(hipEventRecord(pl->ev_in[b], pl->s_h2d), return IXR_ERR_HIP);
+        // decode: needs this group's input, and the output staging buffer copied out (two groups back)
+        HIP_TRY(hipStreamWaitEvent(st, pl->ev_in[b], 0), return IXR_ERR_HIP);
+        if (gi >= 2) HIP_TRY(hipStreamWaitEvent(st, pl->ev_out[b], 0), return IXR_ERR_HIP);
+        // the kernels address packs by arena offset: hand them the staging buffers shifted back by the group's first offset
+        LaunchCtx c{st, pl->d_packs, pl->d_metas, (const uint8_t*)pl->h_din[b] - sp.in_lo, pl->h_dout[b] - sp.out_lo, pl->d_scratch};
+        LaunchCtx cb = c;
+        cb.stream = pl->aux;
+        T.run("k_parse", g.cnt[L_ALL], [&] { launch_parse(c, pl->d_lists + g.off[L_ALL], g.cnt[L_ALL]); });
+        rc = run_group_rows(pl, T, TB, c, cb, g);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(pl->ev_dec[b], st), return IXR_ERR_HIP);
+        // copy out
+        HIP_TRY(hipStreamWaitEvent(pl->s_d2h, pl->ev_dec[b], 0), return IXR_ERR_HIP);
+        HIP_TRY(hipMemcpyAsync(hout + sp.out_lo, pl->h_dout[b], out_len, hipMemcpyDeviceToHost, pl->s_d2h), return IXR_ERR_HIP);
+        HIP_TRY(hipEventRecord(pl->ev_out[b], pl->s_d2h), return IXR_ERR_HIP);
+    }
+    HIP_TRY(hipStreamSynchronize(pl->s_d2h), return IXR_ERR_HIP);
+    HIP_TRY(hipStreamSynchronize(st), return IXR_ERR_HIP);
+    HIP_TRY(hipStreamSynchronize(pl->s_h2d), return IXR_ERR_HIP);
     HIP_TRY(hipGetLastError(), return IXR_ERR_HIP);
     return 0;
 }

@@ -106,6 +106,7 @@ _sig = {
     "ixr_plan_out_bytes": (_u64, [_vp]),
     "ixr_plan_scratch_bytes": (_u64, [_vp]),
     "ixr_plan_run": (_i32, [_vp, _vp, _u64, _vp, _u64, _vp]),
+    "ixr_plan_run_host": (_i32, [_vp, _vp, _u64, _vp, _u64]),
     "ixr_plan_status": (_i32, [_vp, C.POINTER(_i32), _vp]),
     "ixr_plan_totals": (None, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
     "ixr_plan_set_profiling": (None, [_vp, _i32]),
@@ -230,6 +231,23 @@ class DeviceBuffer:
             pass
 
 
+class PinnedBuffer:
+    """page-locked host memory (ixr_host_alloc_pinned) with a numpy view"""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self.ptr = lib.ixr_host_alloc_pinned(self.nbytes)
+        if not self.ptr:
+            raise IxrError(ERR_OUT_OF_MEMORY, "ixr_host_alloc_pinned")
+        self.array = np.ctypeslib.as_array((C.c_uint8 * max(self.nbytes, 1)).from_address(self.ptr))[:self.nbytes]
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            lib.ixr_host_free_pinned(self.ptr)
+            self.ptr = None
+
+
 class Plan:
     """Batch decode plan (ixr_plan_*)."""
 
@@ -253,6 +271,12 @@ class Plan:
         rc = lib.ixr_plan_run(self.handle, d_in, in_bytes, d_out, out_bytes, stream)
         if rc:
             raise IxrError(rc, "ixr_plan_run")
+
+    def run_host(self, h_in, in_bytes, h_out, out_bytes):
+        """ixr_plan_run_host: arenas in host memory (addresses), copies overlapped with the decode"""
+        rc = lib.ixr_plan_run_host(self.handle, h_in, in_bytes, h_out, out_bytes)
+        if rc:
+            raise IxrError(rc, "ixr_plan_run_host")
 
     def run_dict_structs(self, d_in, in_bytes, d_out, out_bytes, ds_off, stream=None):
         arr = (_u64 * self.n)(*[int(x) for x in ds_off])

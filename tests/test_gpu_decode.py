@@ -487,3 +487,48 @@ def test_explicit_stream_repeated_runs_multiple_groups():
         d_in.free()
         d_out.free()
         L.lib.ixr_stream_destroy(0, stream)
+
+
+@pytest.mark.gpu
+def test_host_arenas_pipelined_run_matches_the_device_run():
+    """ixr_plan_run_host: both arenas in pinned host memory, the plan cut into several groups (small scratch budget) that
+    go through two staging buffers per direction.  Every pack's rows must equal the source rows (and therefore what
+    ixr_plan_run leaves on the device); two runs back to back reuse the staging buffers and streams; a pack corrupted in
+    the host arena is reported by ixr_plan_status and spoils no other pack."""
+    reqs = []
+    for pack_id in range(7):
+        for kind in (2, 4, 8, 10, 0, 9, 12):
+            reqs.append((kind, pack_id, 65536 if pack_id < 6 else 4321, 0))
+    descs, arena, out_bytes, sums = L.synth_build(reqs, 0xFACADE, threads=4)
+    plan = L.Plan(0, descs, 24 << 20)  # ~ a dozen groups
+    h_in, h_out = L.PinnedBuffer(len(arena)), L.PinnedBuffer(out_bytes + 16)
+    try:
+        h_in.array[:] = arena
+        for rep in range(2):
+            h_out.array[:] = 0xA5
+            plan.run_host(h_in.ptr, len(arena), h_out.ptr, out_bytes + 16)
+            status, bad = plan.status()
+            assert bad == 0 and all(int(s) == d.pack_size for s, d in zip(status, descs))
+            for (kind, pack_id, rows, _), d in zip(reqs, descs):
+                data = L.synth_column(kind, 0xFACADE, pack_id, rows)
+                assert h_out.array[d.out_off:d.out_off + d.data_size].tobytes() == data.tobytes(), (rep, L.COL_NAMES[kind], pack_id)
+        # a corrupted pack in the middle: its status is negative, every other pack still decodes to its rows
+        victim = len(descs) // 2
+        dv = descs[victim]
+        h_in.array[dv.in_off:dv.in_off + 4] = 0xFF
+        h_out.array[:] = 0
+        plan.run_host(h_in.ptr, len(arena), h_out.ptr, out_bytes + 16)
+        status, bad = plan.status()
+        assert bad >= 1 and int(status[victim]) != dv.pack_size
+        for i, ((kind, pack_id, rows, _), d) in enumerate(zip(reqs, descs)):
+            if int(status[i]) == d.pack_size:
+                data = L.synth_column(kind, 0xFACADE, pack_id, rows)
+                assert h_out.array[d.out_off:d.out_off + d.data_size].tobytes() == data.tobytes(), (L.COL_NAMES[kind], pack_id)
+        assert sum(int(status[i]) != d.pack_size for i, d in enumerate(descs)) == bad
+        # arenas that are too small are refused before anything runs
+        with pytest.raises(L.IxrError):
+            plan.run_host(h_in.ptr, len(arena) - 64, h_out.ptr, out_bytes + 16)
+    finally:
+        plan.destroy()
+        h_in.free()
+        h_out.free()
