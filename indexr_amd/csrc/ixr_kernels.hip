@@ -221,8 +221,12 @@ __device__ __forceinline__ int64_t unzigzag64(uint64_t r) { return (int64_t)((r 
 // wave 2: the RLE id stream); each wave follows its chain through an LDS window.
 // ---------------------------------------------------------------------------------------------------------------
 // Walk one DELTA stream (DeltaCodec.decodeInts/decodeLongs framing, DeltaCodec.java:100-141, 204-245) and write its index.
+// Where a block starts depends on every width byte before it, and a single wave issues one instruction every few cycles,
+// so the serial part does the least it can: it follows the chain (length of the block's varint, four width bytes) and notes
+// each block's position and widths in LDS (`s_blk`, one uint2 per block).  Decoding the block minimum, building the index
+// words and checking the widths then runs one block per lane.
 __device__ int32_t walk_delta(Win& w, uint32_t pack_size, uint32_t off, uint32_t n, int width, int64_t* min_delta, uint32_t* mb,
-                              int64_t* first_out) {
+                              int64_t* first_out, uint2* s_blk) {
     const int lane = threadIdx.x & 63;
     // the arguments are equal in all lanes; say so, so that the chain below stays in scalar registers
     pack_size = __builtin_amdgcn_readfirstlane(pack_size);
@@ -235,35 +239,50 @@ __device__ int32_t walk_delta(Win& w, uint32_t pack_size, uint32_t off, uint32_t
     uint32_t pos = off + 4;
     const uint32_t end = off + 4 + (uint32_t)len;
     int32_t err = 0;
-    const int vb = width == 32 ? 5 : 10;
-    uint64_t raw = win_uvarint(w, pos, end, vb, err);
+    const uint32_t vb = width == 32 ? 5u : 10u, W = (uint32_t)width;
+    uint64_t raw = win_uvarint(w, pos, end, (int)vb, err);
     *first_out = width == 32 ? unzigzag32(raw) : unzigzag64(raw);
+    if (err) return err;
     const uint32_t nb = (n + kBlock - 1) / kBlock;
     // a block is at most 10 + 4 * (1 + 4 * width) bytes: one window check per block, then plain LDS byte reads
-    const uint32_t block_max = 10u + 4u * (1u + 4u * (uint32_t)width) + 16u;
-    for (uint32_t b = 0; b < nb && !err; b++) {
+    const uint32_t block_max = 10u + 4u * (1u + 4u * W) + 16u;
+    for (uint32_t b = 0; b < nb; b++) {
+        // the position is the same in every lane: keeping it (and everything derived from it) in scalar registers makes
+        // the loop's branches scalar branches instead of execution-mask bookkeeping
+        pos = __builtin_amdgcn_readfirstlane(pos);
         if (pos >= end) { err = E_CORRUPT; break; }
         w.need(pos, block_max);
-        const uint32_t b0 = w.u8(pos);
-        if (b0 < 0x80u) { raw = b0; pos++; }                      // one-byte varint: the common case
-        else raw = win_uvarint(w, pos, end, vb, err);
-        if (err) break;
-        const int64_t md = width == 32 ? unzigzag32(raw) : unzigzag64(raw);
+        const uint32_t start = pos;
+        // the varint's length: bytes up to the first one without the continuation bit; it must end inside the stream
+        // and within vb bytes (VarInteger.java:68-96)
+        uint32_t vl = 1;
+        if (w.u8(pos) >= 0x80u) {
+            const uint64_t lo = w.peek64u(pos);
+            const uint64_t stop = ~lo & 0x8080808080808080ull;
+            if (stop) {
+                vl = ((uint32_t)__builtin_ctzll(stop) >> 3) + 1u;
+            } else {
+                const uint32_t hi = (uint32_t)w.peek64u(pos + 8);
+                vl = !(hi & 0x80u) ? 9u : (!(hi & 0x8000u) ? 10u : 11u);
+            }
+            vl = __builtin_amdgcn_readfirstlane(vl);
+            if (vl > min(vb, end - pos)) { err = E_CORRUPT; break; }
+        }
+        pos += vl;
         const uint32_t cnt = min((uint32_t)kBlock, n - b * kBlock);
-        uint32_t word[4] = {0, 0, 0, 0};
+        uint32_t bws = 0;
         if (cnt == (uint32_t)kBlock) {
             // full block: four mini-blocks of 32 values, 4 * bw payload bytes each.  Positions only grow, so running off the
             // stream (or past the 24 bits an index word holds) shows in the final position: one check per block.  Bytes
             // read beyond the stream's end in the meantime come from the window (zero filled past the arena's slack).
-            bool bad_bw = false;
+            // (Reading the candidates for all possible widths at once, to pay one trip to LDS per block instead of four, was
+            // tried: a lone wave is bound by the number of instructions it issues, and that version issues more.)
 #pragma unroll
             for (uint32_t m = 0; m < 4; m++) {
                 const uint32_t bw = w.u8(pos);
-                bad_bw |= bw > (uint32_t)width;
-                word[m] = (pos + 1) | (bw << 24);
-                pos += 1 + 4 * min(bw, (uint32_t)width);
+                bws |= bw << (8 * m);
+                pos += 1 + 4 * min(bw, W);
             }
-            if (bad_bw || pos > end || pos >= (1u << 24)) err = E_CORRUPT;
         } else {
 #pragma unroll
             for (uint32_t m = 0; m < 4; m++) {
@@ -271,19 +290,51 @@ __device__ int32_t walk_delta(Win& w, uint32_t pack_size, uint32_t off, uint32_t
                     const uint32_t c = min((uint32_t)kMini, cnt - m * kMini);
                     if (pos >= end) { err = E_CORRUPT; break; }
                     const uint32_t bw = w.u8(pos);
-                    pos++;
-                    if (bw > (uint32_t)width || pos >= (1u << 24)) { err = E_CORRUPT; break; }
-                    word[m] = pos | (bw << 24);
-                    pos += ((c + 7) >> 3) * bw;
-                    if (pos > end) { err = E_CORRUPT; break; }
+                    bws |= bw << (8 * m);
+                    pos += 1 + ((c + 7) >> 3) * min(bw, W);
                 }
             }
+            if (err) break;
         }
-        if (err) break;
-        if (lane == 0) min_delta[b] = md;
-        if (lane < 4 && (uint32_t)lane * kMini < cnt) mb[b * 4 + lane] = lane == 0 ? word[0] : lane == 1 ? word[1] : lane == 2 ? word[2] : word[3];
+        if (pos > end || pos >= (1u << 24)) { err = E_CORRUPT; break; }
+        if (lane == 0) s_blk[b] = make_uint2(start, bws);
     }
     if (!err && pos != end) err = E_CORRUPT;
+    if (err) return err;
+    Win::wave_lds_sync();
+    // one block per lane: the block minimum (its varint ends inside the stream, as checked above; the 16-byte load may run
+    // into the arena's slack), the four index words, the width check
+    bool bad = false;
+    for (uint32_t b = lane; b < nb; b += 64) {
+        const uint2 rec = s_blk[b];
+        uint4 head;
+        __builtin_memcpy(&head, w.base + rec.x, 16);
+        const uint32_t hw[4] = {head.x, head.y, head.z, head.w};
+        uint64_t v = 0;
+        uint32_t used = 0;
+        bool open = true;
+#pragma unroll
+        for (uint32_t i = 0; i < 10; i++) {
+            const uint32_t byte = (hw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            if (open) { v |= (uint64_t)(byte & 0x7Fu) << (7 * i); used = i + 1; }
+            open = open && (byte & 0x80u);
+        }
+        const int64_t md = width == 32 ? unzigzag32(v) : unzigzag64(v);
+        const uint32_t cnt = min((uint32_t)kBlock, n - b * kBlock);
+        uint32_t p = rec.x + used;
+        min_delta[b] = md;
+#pragma unroll
+        for (uint32_t m = 0; m < 4; m++) {
+            if (m * kMini < cnt) {
+                const uint32_t c = min((uint32_t)kMini, cnt - m * kMini);
+                const uint32_t bw = (rec.y >> (8 * m)) & 0xFFu;
+                bad |= bw > W;
+                mb[b * 4 + m] = (p + 1) | (bw << 24);
+                p += 1 + ((c + 7) >> 3) * min(bw, W);
+            }
+        }
+    }
+    if (__ballot(bad)) err = E_CORRUPT;
     return err;
 }
 
@@ -665,6 +716,7 @@ __global__ __launch_bounds__(256) void k_parse(const DevPack* __restrict__ packs
                                                PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                uint8_t* __restrict__ scratch) {
     __shared__ __align__(16) uint8_t s_win[3][kWinAlloc];
+    __shared__ uint2 s_blk[2][65536 / kBlock];  // per DELTA stream: position and widths of every block
     __shared__ int32_t s_werr[4];
     __shared__ int64_t s_first[2];
     const int k = threadIdx.x >> 6;  // wave = stream
@@ -693,7 +745,7 @@ __global__ __launch_bounds__(256) void k_parse(const DevPack* __restrict__ packs
         if (k < 2 && sd.n) {
             int64_t* md = (int64_t*)(scratch + (k == 0 ? P.s_idx[0] : P.s_idx[1]));
             uint32_t* mb = (uint32_t*)(md + (P.obj_count + kBlock - 1) / kBlock);
-            werr = walk_delta(w, psz, sd.in_off, sd.n, W ? W : 32, md, mb, &first);
+            werr = walk_delta(w, psz, sd.in_off, sd.n, W ? W : 32, md, mb, &first, s_blk[k]);
         } else if (k == 2 && has_ids) {
             werr = walk_rle(w, m.ids_off, m.ids_len, n, m.id_bw, (uint4*)(scratch + P.s_restart));
         }
