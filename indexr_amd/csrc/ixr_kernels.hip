@@ -20,6 +20,7 @@
 //   k_dict_num   one wave per 1024-row tile: expand ids from the tile's segment record, gather dictionary entries, store rows.
 //   string packs k_str_dict_scan -> k_front_decode -> k_str_index -> k_str_copy  (see each kernel)
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include <type_traits>
 
@@ -82,7 +83,7 @@ __device__ __forceinline__ uint32_t bit_width32(uint32_t v) { return v ? 32u - (
 #ifndef IXR_FUSED_CHUNKS
 #define IXR_FUSED_CHUNKS 4      // 16-byte chunks per lane and step of k_str_fused
 #endif
-constexpr int kParseLaneThreshold = 16384;  // packs per launch from which k_parse_lanes is used
+constexpr int kParseLaneThreshold = 16384;  // packs per launch from which k_parse_lanes is used (plans of mostly string packs: earlier)
 constexpr uint32_t kWin = 4096;
 constexpr uint32_t kSegTab = 128;                      // short-segment table of the RLE tile expansion (uint2 entries)
 constexpr uint32_t kWinAlloc = kWin + 16 + 8 * kSegTab;  // bytes of LDS per window: data, 16 spare bytes so that 12-byte peeks
@@ -129,6 +130,8 @@ struct Win {
         wave_lds_sync();
         w0 = __builtin_amdgcn_readfirstlane(pos & ~15u);
         // all chunk loads are issued before the first is consumed: out-of-range chunks re-read the last valid one
+        // (loading only the kilobytes a tile is expected to need was measured: 3 to 15 % slower, the chunk loads then sit
+        // behind branches)
         uint4 v[kWin / 1024];
 #pragma unroll
         for (uint32_t i = 0; i < kWin / 1024; i++) {
@@ -223,7 +226,7 @@ __device__ __forceinline__ int64_t unzigzag64(uint64_t r) { return (int64_t)((r 
 // Walk one DELTA stream (DeltaCodec.decodeInts/decodeLongs framing, DeltaCodec.java:100-141, 204-245) and write its index.
 // Where a block starts depends on every width byte before it, and a single wave issues one instruction every few cycles,
 // so the serial part does the least it can: it follows the chain (length of the block's varint, four width bytes) and notes
-// each block's position and widths in LDS (`s_blk`, one uint2 per block).  Decoding the block minimum, building the index
+// each block's position and widths in LDS (`s_blk`, one uint2 per block, 64 blocks a round).  Decoding the block minimum, building the index
 // words and checking the widths then runs one block per lane.
 __device__ int32_t walk_delta(Win& w, uint32_t pack_size, uint32_t off, uint32_t n, int width, int64_t* min_delta, uint32_t* mb,
                               int64_t* first_out, uint2* s_blk) {
@@ -246,7 +249,10 @@ __device__ int32_t walk_delta(Win& w, uint32_t pack_size, uint32_t off, uint32_t
     const uint32_t nb = (n + kBlock - 1) / kBlock;
     // a block is at most 10 + 4 * (1 + 4 * width) bytes: one window check per block, then plain LDS byte reads
     const uint32_t block_max = 10u + 4u * (1u + 4u * W) + 16u;
-    for (uint32_t b = 0; b < nb; b++) {
+    bool bad = false;
+    for (uint32_t b0 = 0; b0 < nb && !err; b0 += 64) {
+    const uint32_t b1 = min(nb, b0 + 64u);
+    for (uint32_t b = b0; b < b1; b++) {
         // the position is the same in every lane: keeping it (and everything derived from it) in scalar registers makes
         // the loop's branches scalar branches instead of execution-mask bookkeeping
         pos = __builtin_amdgcn_readfirstlane(pos);
@@ -297,16 +303,15 @@ __device__ int32_t walk_delta(Win& w, uint32_t pack_size, uint32_t off, uint32_t
             if (err) break;
         }
         if (pos > end || pos >= (1u << 24)) { err = E_CORRUPT; break; }
-        if (lane == 0) s_blk[b] = make_uint2(start, bws);
+        if (lane == 0) s_blk[b - b0] = make_uint2(start, bws);
     }
-    if (!err && pos != end) err = E_CORRUPT;
-    if (err) return err;
+    if (err) break;
     Win::wave_lds_sync();
     // one block per lane: the block minimum (its varint ends inside the stream, as checked above; the 16-byte load may run
     // into the arena's slack), the four index words, the width check
-    bool bad = false;
-    for (uint32_t b = lane; b < nb; b += 64) {
-        const uint2 rec = s_blk[b];
+    const uint32_t b = b0 + lane;
+    if (b < b1) {
+        const uint2 rec = s_blk[lane];
         uint4 head;
         __builtin_memcpy(&head, w.base + rec.x, 16);
         const uint32_t hw[4] = {head.x, head.y, head.z, head.w};
@@ -334,6 +339,10 @@ __device__ int32_t walk_delta(Win& w, uint32_t pack_size, uint32_t off, uint32_t
             }
         }
     }
+    Win::wave_lds_sync();  // the table is read before the next round overwrites it
+    }
+    if (!err && pos != end) err = E_CORRUPT;
+    if (err) return err;
     if (__ballot(bad)) err = E_CORRUPT;
     return err;
 }
@@ -716,7 +725,7 @@ __global__ __launch_bounds__(256) void k_parse(const DevPack* __restrict__ packs
                                                PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                uint8_t* __restrict__ scratch) {
     __shared__ __align__(16) uint8_t s_win[3][kWinAlloc];
-    __shared__ uint2 s_blk[2][65536 / kBlock];  // per DELTA stream: position and widths of every block
+    __shared__ uint2 s_blk[2][64];  // per DELTA stream: position and widths of the blocks of one round
     __shared__ int32_t s_werr[4];
     __shared__ int64_t s_first[2];
     const int k = threadIdx.x >> 6;  // wave = stream
@@ -1872,7 +1881,9 @@ __global__ __launch_bounds__(256) void k_str_copy(const DevPack* __restrict__ pa
 // k_str_fused: row index and body copy of string dictionary packs in one kernel, one WAVE per tile of kRleTile rows; no
 // workgroup barrier anywhere.  The wave expands its tile's ids, looks the rows' dictionary slices up, scans the row lengths
 // (the tile's first offset comes from k_str_index<.., true>, which leaves one word per tile instead of eight bytes per
-// row), writes the tile's part of the output index and keeps the rows' offsets in LDS; then it produces the tile's stretch
+// row; having every tile publish its byte count and look back at the tiles before it instead was measured: the round trips
+// of the device-scope atomics under a saturated store stream cost three times what the small kernel does),
+// writes the tile's part of the output index and keeps the rows' offsets in LDS; then it produces the tile's stretch
 // of the body in 16-byte aligned chunks exactly as k_str_copy does (row of the chunk's first byte by binary search in
 // LDS, one unaligned 16-byte load per row that overlaps the chunk, merged under byte masks, full-width streaming stores).
 // Nothing about the rows is read back from memory: what a copy kernel gets from HBM at the head of its dependency chain
@@ -2789,7 +2800,8 @@ static inline unsigned cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }
 void launch_parse(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;
     // below this many packs the chip is not full of walker waves and the faster steps of the window version win
-    if (count >= kParseLaneThreshold) {
+    const int lanes_from = c.lane_walk_from > 0 ? c.lane_walk_from : kParseLaneThreshold;
+    if (count >= lanes_from) {
         hipLaunchKernelGGL(k_parse_lanes, dim3(cdiv((unsigned)count * 4, 256)), dim3(256), 0, c.stream, c.packs, list, count, c.metas,
                            c.in, c.scratch);
         return;

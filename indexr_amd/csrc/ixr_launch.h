@@ -18,6 +18,7 @@ struct LaunchCtx {
     uint8_t* out;          // output arena
     uint8_t* scratch;      // scratch base of the current group
     int dict_only = 0;     // 1: build dictionaries only; packs whose decode writes straight to the output arena are skipped
+    int lane_walk_from = 0;  // framing walk: packs per launch from which one lane (not one wave) follows a stream; 0 = default
 };
 
 // ---- the batch that allocates nothing: descriptors travel as a kernel argument, every working array lives in one
