@@ -109,11 +109,15 @@ __device__ __forceinline__ uint4 uniform_load<uint4>(const uint4* p) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-struct Win {
+template <uint32_t kW, uint32_t kTab>
+struct WinT {
+    static constexpr uint32_t kBytes = kW;                    // bytes of the pack the window holds
+    static constexpr uint32_t kTabN = kTab;                   // entries of the short-segment table behind it
+    static constexpr uint32_t kAlloc = kW + 16 + 8 * kTab;    // bytes of LDS: data, 16 spare bytes, segment table
     const uint8_t* base;  // pack start in global memory, 16-byte aligned
     uint32_t limit16;     // bytes readable from `base` in whole 16-byte chunks (pack + arena slack, rounded down)
-    uint8_t* lds;         // kWinAlloc bytes, 16-byte aligned
-    uint32_t w0;          // pack offset held by lds[0]; the window is [w0, w0 + kWin)
+    uint8_t* lds;         // kAlloc bytes, 16-byte aligned
+    uint32_t w0;          // pack offset held by lds[0]; the window is [w0, w0 + kW)
 
     __device__ __forceinline__ void init(const uint8_t* b, uint32_t pack_size, uint8_t* l) {
         base = b; limit16 = __builtin_amdgcn_readfirstlane((pack_size + kInSlack) & ~15u); lds = l; w0 = 0xFFFFFFFFu;
@@ -132,22 +136,22 @@ struct Win {
         // all chunk loads are issued before the first is consumed: out-of-range chunks re-read the last valid one
         // (loading only the kilobytes a tile is expected to need was measured: 3 to 15 % slower, the chunk loads then sit
         // behind branches)
-        uint4 v[kWin / 1024];
+        uint4 v[kW / 1024];
 #pragma unroll
-        for (uint32_t i = 0; i < kWin / 1024; i++) {
+        for (uint32_t i = 0; i < kW / 1024; i++) {
             const uint32_t off = w0 + i * 1024 + lane * 16;  // multiple of 16, so an in-range chunk ends <= limit16
             v[i] = *(const uint4*)(base + min(off, limit16 - 16u));
             if (off >= limit16) v[i] = make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
-        for (uint32_t i = 0; i < kWin / 1024; i++) *(uint4*)(lds + i * 1024 + lane * 16) = v[i];
-        if (lane == 0) *(uint4*)(lds + kWin) = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = 0; i < kW / 1024; i++) *(uint4*)(lds + i * 1024 + lane * 16) = v[i];
+        if (lane == 0) *(uint4*)(lds + kW) = make_uint4(0, 0, 0, 0);
         wave_lds_sync();
     }
-    __device__ __forceinline__ bool has(uint32_t pos, uint32_t bytes) const { return pos >= w0 && pos + bytes <= w0 + kWin; }
-    // make [pos, pos + bytes) part of the window (bytes <= kWin - 16)
+    __device__ __forceinline__ bool has(uint32_t pos, uint32_t bytes) const { return pos >= w0 && pos + bytes <= w0 + kW; }
+    // make [pos, pos + bytes) part of the window (bytes <= kW - 16)
     __device__ __forceinline__ void need(uint32_t pos, uint32_t bytes) {
-        if (pos < w0 || pos + bytes > w0 + kWin) load(pos);
+        if (pos < w0 || pos + bytes > w0 + kW) load(pos);
     }
     // The walkers below read the same address in every lane; readfirstlane tells the compiler so, which keeps the whole
     // chain (positions, widths, branches) in scalar registers and scalar branches.
@@ -186,6 +190,8 @@ struct Win {
         return (uint32_t)(w >> sh) & ((1u << bw) - 1u);
     }
 };
+using Win = WinT<kWin, kSegTab>;  // the window of every kernel but the fused string kernel
+
 
 // VarInteger.readUnsignedVarInt / readUnsignedVarLong (VarInteger.java:68-96) out of the window: at most `max_bytes`
 // (5 or 10) bytes, none at or beyond `end`.  Returns the value, advances pos; sets err when the varint runs off the stream
@@ -972,7 +978,8 @@ __device__ __forceinline__ void pack_block_remap(uint32_t& bx, uint32_t& by) {
 // stream into its LDS window with one coalesced load and walks the remaining segment headers there.  The consumers read
 // the ids back in the order that suits their stores, which also lets them keep 16 independent gathers in flight.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void rle_tile_expand(Win& w, uint32_t bw, uint32_t ids_end, uint4 seg, uint32_t tile_start,
+template <class WinX>
+__device__ __forceinline__ void rle_tile_expand(WinX& w, uint32_t bw, uint32_t ids_end, uint4 seg, uint32_t tile_start,
                                                 uint32_t tile_end, uint16_t* ids) {
     const int lane = threadIdx.x & 63;
     bw = __builtin_amdgcn_readfirstlane(bw);
@@ -990,11 +997,11 @@ __device__ __forceinline__ void rle_tile_expand(Win& w, uint32_t bw, uint32_t id
     // CU's single scalar unit, shared by all its waves, so the walk does the minimum per segment: short segments (<= 64 rows)
     // are only noted in a table (x: payload position or run value; y: first row in the tile | rows << 10 | rows to skip << 17 |
     // packed << 23) and expanded afterwards with one lane per segment.  Long segments are expanded by the whole wave at once.
-    uint2* tab = (uint2*)(w.lds + kWin + 16);
+    uint2* tab = (uint2*)(w.lds + WinX::kBytes + 16);
     uint32_t nseg = 0;
     auto flush = [&]() {
         if (nseg == 0) return;
-        Win::wave_lds_sync();
+        WinX::wave_lds_sync();
         for (uint32_t s = lane; s < nseg; s += 64) {
             const uint2 e = tab[s];
             const uint32_t r0 = e.y & 1023u, rows = (e.y >> 10) & 127u, skip = (e.y >> 17) & 63u;
@@ -1005,7 +1012,7 @@ __device__ __forceinline__ void rle_tile_expand(Win& w, uint32_t bw, uint32_t id
             }
         }
         nseg = 0;
-        Win::wave_lds_sync();
+        WinX::wave_lds_sync();
     };
     while (true) {
         const uint32_t lo = max(o, tile_start), hi = min(o + cnt, tile_end);
@@ -1017,14 +1024,19 @@ __device__ __forceinline__ void rle_tile_expand(Win& w, uint32_t bw, uint32_t id
                 }
                 if (lane == 0) tab[nseg] = make_uint2(packed ? dpos : val, (lo - tile_start) | ((hi - lo) << 10) | ((lo - o) << 17) | ((uint32_t)packed << 23));
                 nseg++;
-                if (nseg == kSegTab) flush();
+                if (nseg == WinX::kTabN) flush();
             } else if (packed) {
-                // bytes holding rows [lo, hi) of this segment; at most kRleTile * 16 bits, well inside a window
-                const uint32_t b0 = dpos + (((lo - o) * bw) >> 3);
-                const uint32_t b1 = dpos + (((hi - o) * bw + 7) >> 3);
-                if (!w.has(b0, b1 - b0 + 8)) { flush(); w.load(b0); }
+                // bytes holding rows [lo, hi) of this segment: at most kRleTile * 16 bits; a window smaller than that takes
+                // the rows in stretches that fit (a stretch starts at most 15 bytes into the window, reads run 8 bytes over)
+                const uint32_t rows_per = (((WinX::kBytes - 48u) * 8u) / max(bw, 1u)) & ~63u;
+                for (uint32_t l2 = lo; l2 < hi; l2 += rows_per) {
+                    const uint32_t h2 = min(hi, l2 + rows_per);
+                    const uint32_t b0 = dpos + (((l2 - o) * bw) >> 3);
+                    const uint32_t b1 = dpos + (((h2 - o) * bw + 7) >> 3);
+                    if (!w.has(b0, b1 - b0 + 8)) { flush(); w.load(b0); }
 #pragma unroll 4
-                for (uint32_t i = lo + lane; i < hi; i += 64) ids[i - tile_start] = (uint16_t)w.bits(dpos, (i - o) * bw, bw);
+                    for (uint32_t i = l2 + lane; i < h2; i += 64) ids[i - tile_start] = (uint16_t)w.bits(dpos, (i - o) * bw, bw);
+                }
             } else {
                 for (uint32_t i = lo + lane; i < hi; i += 64) ids[i - tile_start] = (uint16_t)val;
             }
@@ -1059,7 +1071,7 @@ __device__ __forceinline__ void rle_tile_expand(Win& w, uint32_t bw, uint32_t id
     }
     flush();
     // the tile's ids were written by this wave only and are read by this wave only
-    Win::wave_lds_sync();
+    WinX::wave_lds_sync();
 }
 
 // Common prologue of the tile kernels: which pack / tile this wave owns. Returns false when there is nothing to do.
@@ -1890,10 +1902,22 @@ __global__ __launch_bounds__(256) void k_str_copy(const DevPack* __restrict__ pa
 // is what it waits for, and per-row offsets are 8 bytes for every ~55 the body holds.
 // (DictStruct.decodeStrings, DictStruct.java:97-110; StringsStruct.Builder, StringsStruct.java:120-158.)
 // ---------------------------------------------------------------------------------------------------------------
-constexpr uint32_t kFusedWaveLds = 8224;  // per wave: stream window + id tile while expanding (7184), then offsets[1025] + deltas[1024]
-static_assert(kFusedWaveLds >= kWinAlloc + 2 * kRleTile && kFusedWaveLds >= 4 * (2 * kRleTile + 1) + 16 && kFusedWaveLds % 16 == 0, "LDS layout");
+#ifndef IXR_FUSED_PASS_ROWS
+#define IXR_FUSED_PASS_ROWS 512  // rows whose offsets are in LDS at a time (256, 512 or 1024)
+#endif
+// The kernel waits for gathers that miss L2, so what it needs is waves: the LDS of a wave is kept small (a 2 KB stream window
+// instead of the usual 4 KB, the row offsets of half a tile at a time) so that eight workgroups fit a compute unit.
+using FusedWin = WinT<2048, 64>;
+constexpr uint32_t kFusedPassRows = IXR_FUSED_PASS_ROWS;
+constexpr uint32_t kFusedDltOff = (4 * (kFusedPassRows + 1) + 15) & ~15u;  // the deltas start 16-byte aligned behind the offsets
+constexpr uint32_t kFusedWaveLds =                      // per wave: stream window + id tile while expanding, then offsets[] + deltas[]
+    ((FusedWin::kAlloc + 2 * kRleTile > kFusedDltOff + 4 * kFusedPassRows ? FusedWin::kAlloc + 2 * kRleTile : kFusedDltOff + 4 * kFusedPassRows) + 15) & ~15u;
+static_assert(kRleTile % kFusedPassRows == 0 && kFusedPassRows % 256 == 0, "a pass is a whole number of 256-row groups");
 
-__global__ __launch_bounds__(256) void k_str_fused(const DevPack* __restrict__ packs, const int* __restrict__ list,
+#ifndef IXR_FUSED_WAVES_PER_SIMD
+#define IXR_FUSED_WAVES_PER_SIMD 6
+#endif
+__global__ __launch_bounds__(256, IXR_FUSED_WAVES_PER_SIMD) void k_str_fused(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                    const PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                    uint8_t* __restrict__ out, const uint8_t* __restrict__ scratch) {
     __shared__ __align__(16) uint8_t smem[4][kFusedWaveLds];
@@ -1919,11 +1943,11 @@ __global__ __launch_bounds__(256) void k_str_fused(const DevPack* __restrict__ p
     const uint32_t tbase = uniform_load((const uint32_t*)(scratch + P.s_rows) + tile);  // offset of the tile's first row
     uint8_t* wl = smem[wave];
 
-    // ---- the tile's ids, the rows' dictionary slices, the scan of their lengths
+    // ---- the tile's ids and the rows' dictionary slices
     uint2 ab[16];
     {
-        uint16_t* ids = (uint16_t*)(wl + kWinAlloc);
-        Win w;
+        uint16_t* ids = (uint16_t*)(wl + FusedWin::kAlloc);
+        FusedWin w;
         w.init(in + P.in_off, (uint32_t)P.pack_size, wl);
         rle_tile_expand(w, M.id_bw, M.ids_off + 4 + M.ids_len, uniform_load((const uint4*)(scratch + P.s_restart) + tile), tile_start,
                         tile_end, ids);
@@ -1938,15 +1962,25 @@ __global__ __launch_bounds__(256) void k_str_fused(const DevPack* __restrict__ p
                 __builtin_memcpy(&ab[q * 4 + g], doff + id, 8);  // doff[id], doff[id + 1]
             }
         }
-        Win::wave_lds_sync();  // the id tile and the window are dead: their memory becomes the offset tables
+        FusedWin::wave_lds_sync();  // the id tile and the window are dead: their memory becomes the offset tables
     }
-    uint32_t* s_off = (uint32_t*)wl;                    // [cnt + 1] shifted output offsets of the tile's rows
-    uint32_t* s_dlt = (uint32_t*)(wl + 4 * (kRleTile + 1) + 12);  // [cnt] srcOff - s_off + 16 (mod 2^32), 16-byte aligned
-    {
-        uint32_t run = tbase + A;
+    uint32_t* s_off = (uint32_t*)wl;                   // [rows + 1] shifted output offsets of the pass's rows
+    uint32_t* s_dlt = (uint32_t*)(wl + kFusedDltOff);  // [rows] srcOff - s_off + 16 (mod 2^32)
+    const uint8_t* dbody16 = dbody - 16;  // chunk byte k of row r comes from dbody16[s_dlt[r] + cpos + k]; the sum is >= 1
+    uint32_t run = tbase + A;
+    constexpr int kGroups = kFusedPassRows / 256;  // 256-row groups per pass
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t r = q * 256 + 4 * lane;
+    for (int pass = 0; pass < (int)(kRleTile / kFusedPassRows); pass++) {
+        const uint32_t pass_first = pass * kFusedPassRows;
+        if (pass_first >= cnt) break;
+        const uint32_t rows = min(cnt - pass_first, kFusedPassRows);
+        // ---- scan of the row lengths: the output index leaves as 16-byte stores, the shifted offsets and the source deltas
+        // of the pass's rows go to LDS
+#pragma unroll
+        for (int qq = 0; qq < kGroups; qq++) {
+            const int q = pass * kGroups + qq;
+            const uint32_t r = q * 256 + 4 * lane;   // row in the tile
+            const uint32_t rl = r - pass_first;      // row in the pass
             uint32_t len[4], ex[4], s4 = 0;
 #pragma unroll
             for (int g = 0; g < 4; g++) {
@@ -1959,7 +1993,6 @@ __global__ __launch_bounds__(256) void k_str_fused(const DevPack* __restrict__ p
 #pragma unroll
             for (int g = 0; g < 4; g++) ex[g] += first;
             run += __builtin_amdgcn_readlane(inc, 63);
-            // the output index (unshifted) leaves as 16-byte stores; the shifted offsets and the source deltas go to LDS
             if (r + 3 < cnt) {
                 *(uint4*)(off + tile_start + r) = make_uint4(ex[0] - A, ex[1] - A, ex[2] - A, ex[3] - A);
             } else {
@@ -1968,80 +2001,78 @@ __global__ __launch_bounds__(256) void k_str_fused(const DevPack* __restrict__ p
                     if (r + g < cnt) off[tile_start + r + g] = ex[g] - A;
             }
             if (r < cnt) {  // rows past the tile's end have length 0: their entries equal the tile's end offset
-                *(uint4*)(s_off + r) = make_uint4(ex[0], ex[1], ex[2], ex[3]);
-                *(uint4*)(s_dlt + r) = make_uint4(ab[q * 4].x - ex[0] + 16u, ab[q * 4 + 1].x - ex[1] + 16u, ab[q * 4 + 2].x - ex[2] + 16u,
-                                                  ab[q * 4 + 3].x - ex[3] + 16u);
+                *(uint4*)(s_off + rl) = make_uint4(ex[0], ex[1], ex[2], ex[3]);
+                *(uint4*)(s_dlt + rl) = make_uint4(ab[q * 4].x - ex[0] + 16u, ab[q * 4 + 1].x - ex[1] + 16u, ab[q * 4 + 2].x - ex[2] + 16u,
+                                                   ab[q * 4 + 3].x - ex[3] + 16u);
             }
         }
-        if (lane == 0) s_off[cnt] = run;
-        Win::wave_lds_sync();
-    }
-    const uint32_t rows = cnt;
-    const uint32_t b0 = s_off[0], b1 = s_off[rows];
-    if (b1 <= b0) return;
-    const uint8_t* dbody16 = dbody - 16;  // chunk byte k of row r comes from dbody16[s_dlt[r] + cpos + k]; the sum is >= 1
+        if (lane == 0) s_off[rows] = run;
+        FusedWin::wave_lds_sync();
+        const uint32_t b0 = s_off[0], b1 = s_off[rows];
 
-    // One 16-byte chunk: finish it given the row `r` of its first byte; handles chunks that straddle rows.
-    auto finish = [&](uint32_t cpos, uint32_t first, uint32_t cend, uint32_t r, uint4 w) {
-        uint32_t rend = s_off[r + 1];
-        uint32_t pos = min(cend, rend);
-        if (pos < cend) {
-            uint64_t wlo = (uint64_t)w.x | ((uint64_t)w.y << 32), whi = (uint64_t)w.z | ((uint64_t)w.w << 32);
-            while (pos < cend) {
-                do { r++; rend = s_off[r + 1]; } while (rend <= pos && r + 1 < rows);  // next row that is not empty
-                const uint32_t segend = min(cend, max(rend, pos + 1));
-                const uint4 v = ld16u(dbody16 + (uint32_t)(s_dlt[r] + cpos));
-                const int a = (int)(pos - cpos), e = (int)(segend - cpos);
-                const uint64_t ml = low_bytes(e) & ~low_bytes(a), mh = low_bytes(e - 8) & ~low_bytes(a - 8);
-                wlo = (wlo & ~ml) | (((uint64_t)v.x | ((uint64_t)v.y << 32)) & ml);
-                whi = (whi & ~mh) | (((uint64_t)v.z | ((uint64_t)v.w << 32)) & mh);
-                pos = segend;
+        // One 16-byte chunk: finish it given the row `r` of its first byte; handles chunks that straddle rows.
+        auto finish = [&](uint32_t cpos, uint32_t first, uint32_t cend, uint32_t r, uint4 w) {
+            uint32_t rend = s_off[r + 1];
+            uint32_t pos = min(cend, rend);
+            if (pos < cend) {
+                uint64_t wlo = (uint64_t)w.x | ((uint64_t)w.y << 32), whi = (uint64_t)w.z | ((uint64_t)w.w << 32);
+                while (pos < cend) {
+                    do { r++; rend = s_off[r + 1]; } while (rend <= pos && r + 1 < rows);  // next row that is not empty
+                    const uint32_t segend = min(cend, max(rend, pos + 1));
+                    const uint4 v = ld16u(dbody16 + (uint32_t)(s_dlt[r] + cpos));
+                    const int a = (int)(pos - cpos), e = (int)(segend - cpos);
+                    const uint64_t ml = low_bytes(e) & ~low_bytes(a), mh = low_bytes(e - 8) & ~low_bytes(a - 8);
+                    wlo = (wlo & ~ml) | (((uint64_t)v.x | ((uint64_t)v.y << 32)) & ml);
+                    whi = (whi & ~mh) | (((uint64_t)v.z | ((uint64_t)v.w << 32)) & mh);
+                    pos = segend;
+                }
+                w = make_uint4((uint32_t)wlo, (uint32_t)(wlo >> 32), (uint32_t)whi, (uint32_t)(whi >> 32));
             }
-            w = make_uint4((uint32_t)wlo, (uint32_t)(wlo >> 32), (uint32_t)whi, (uint32_t)(whi >> 32));
-        }
-        if (first == cpos && cend == cpos + 16u) {
-            st16_stream(base16 + cpos, w);
-        } else {  // the tile's first and last chunk are shared with the neighbouring tiles
-            const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
+            if (first == cpos && cend == cpos + 16u) {
+                st16_stream(base16 + cpos, w);
+            } else {  // the first and the last chunk of a pass are shared with the neighbouring pass or tile
+                const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const uint32_t q = cpos + k;
-                if (q >= first && q < cend) base16[q] = (uint8_t)(wv[k >> 2] >> (8 * (k & 3)));
+                for (int k = 0; k < 16; k++) {
+                    const uint32_t q = cpos + k;
+                    if (q >= first && q < cend) base16[q] = (uint8_t)(wv[k >> 2] >> (8 * (k & 3)));
+                }
             }
-        }
-    };
+        };
 
-    // kFusedChunks chunks per lane and step (1 KiB apart, so that each store instruction of the wave stays contiguous): the
-    // row searches run in one branch-free loop and all first loads are in flight together.
-    constexpr int U = IXR_FUSED_CHUNKS;
-    for (uint32_t c0 = (b0 & ~15u) + 16u * lane; c0 < b1; c0 += U * 16u * 64u) {
-        uint32_t cp[U], fp[U], ep[U], rr[U];
-        bool has[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            cp[u] = c0 + u * 16u * 64u;
-            has[u] = cp[u] < b1;
-            if (!has[u]) cp[u] = c0;  // lanes past the end repeat their first chunk's search and load, and store nothing
-            fp[u] = max(cp[u], b0);
-            ep[u] = min(cp[u] + 16u, b1);
-            rr[u] = 0;
-        }
-        // largest r in [0, rows) with s_off[r] <= first: s_off[0] = b0 <= first < b1 = s_off[rows]
-#pragma unroll
-        for (uint32_t step = kRleTile / 2; step >= 1; step >>= 1) {
+        // U chunks per lane and step (1 KiB apart, so that each store instruction of the wave stays contiguous): the
+        // row searches run in one branch-free loop and all first loads are in flight together.
+        constexpr int U = IXR_FUSED_CHUNKS;
+        for (uint32_t c0 = (b0 & ~15u) + 16u * lane; c0 < b1; c0 += U * 16u * 64u) {
+            uint32_t cp[U], fp[U], ep[U], rr[U];
+            bool has[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const uint32_t c = rr[u] + step;
-                const uint32_t o = s_off[min(c, rows)];
-                if (c < rows && o <= fp[u]) rr[u] = c;
+                cp[u] = c0 + u * 16u * 64u;
+                has[u] = cp[u] < b1;
+                if (!has[u]) cp[u] = c0;  // lanes past the end repeat their first chunk's search and load, and store nothing
+                fp[u] = max(cp[u], b0);
+                ep[u] = min(cp[u] + 16u, b1);
+                rr[u] = 0;
             }
+            // largest r in [0, rows) with s_off[r] <= first: s_off[0] = b0 <= first < b1 = s_off[rows]
+#pragma unroll
+            for (uint32_t step = kFusedPassRows / 2; step >= 1; step >>= 1) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint32_t c = rr[u] + step;
+                    const uint32_t o = s_off[min(c, rows)];
+                    if (c < rows && o <= fp[u]) rr[u] = c;
+                }
+            }
+            uint4 w[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) w[u] = ld16u(dbody16 + (uint32_t)(s_dlt[rr[u]] + cp[u]));
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (has[u]) finish(cp[u], fp[u], ep[u], rr[u], w[u]);
         }
-        uint4 w[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) w[u] = ld16u(dbody16 + (uint32_t)(s_dlt[rr[u]] + cp[u]));
-#pragma unroll
-        for (int u = 0; u < U; u++)
-            if (has[u]) finish(cp[u], fp[u], ep[u], rr[u], w[u]);
+        FusedWin::wave_lds_sync();  // the next pass overwrites the tables
     }
 }
 
