@@ -85,9 +85,7 @@ __device__ __forceinline__ uint32_t bit_width32(uint32_t v) { return v ? 32u - (
 #endif
 constexpr int kParseLaneThreshold = 16384;  // packs per launch from which k_parse_lanes is used (plans of mostly string packs: earlier)
 constexpr uint32_t kWin = 4096;
-constexpr uint32_t kSegTab = 128;                      // short-segment table of the RLE tile expansion (uint2 entries)
-constexpr uint32_t kWinAlloc = kWin + 16 + 8 * kSegTab;  // bytes of LDS per window: data, 16 spare bytes so that 12-byte peeks
-                                                        // never run off, and the segment table
+constexpr uint32_t kWinAlloc = kWin + 16;  // bytes of LDS per window: data and 16 spare bytes so that 12-byte peeks never run off
 
 // A wave-uniform 64-bit value, known to the compiler as such (kept in scalar registers).
 __device__ __forceinline__ uint64_t uniform64(uint64_t a) {
@@ -109,11 +107,10 @@ __device__ __forceinline__ uint4 uniform_load<uint4>(const uint4* p) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-template <uint32_t kW, uint32_t kTab>
+template <uint32_t kW>
 struct WinT {
     static constexpr uint32_t kBytes = kW;                    // bytes of the pack the window holds
-    static constexpr uint32_t kTabN = kTab;                   // entries of the short-segment table behind it
-    static constexpr uint32_t kAlloc = kW + 16 + 8 * kTab;    // bytes of LDS: data, 16 spare bytes, segment table
+    static constexpr uint32_t kAlloc = kW + 16;               // bytes of LDS: data, 16 spare bytes
     const uint8_t* base;  // pack start in global memory, 16-byte aligned
     uint32_t limit16;     // bytes readable from `base` in whole 16-byte chunks (pack + arena slack, rounded down)
     uint8_t* lds;         // kAlloc bytes, 16-byte aligned
@@ -190,7 +187,7 @@ struct WinT {
         return (uint32_t)(w >> sh) & ((1u << bw) - 1u);
     }
 };
-using Win = WinT<kWin, kSegTab>;  // the window of every kernel but the fused string kernel
+using Win = WinT<kWin>;  // the window of every kernel but the fused string kernel
 
 
 // VarInteger.readUnsignedVarInt / readUnsignedVarLong (VarInteger.java:68-96) out of the window: at most `max_bytes`
@@ -353,12 +350,69 @@ __device__ int32_t walk_delta(Win& w, uint32_t pack_size, uint32_t off, uint32_t
     return err;
 }
 
-// Walk the RLE/bit-packing hybrid id stream (RLEPackingHybridCodec.decodeInts, RLEPackingHybridCodec.java:97-128) and
-// record, for every tile of kRleTile rows, the segment that covers the tile's first row:
+// ---------------------------------------------------------------------------------------------------------------
+// RLE/bit-packing hybrid id stream (RLEPackingHybridCodec.decodeInts, RLEPackingHybridCodec.java:97-128): a chain of
+// segments, each an unsigned varint header h (count = h >>> 1; h & 1: bit-packed, else a run) followed by
+// ceil(count / 8) * bitWidth bytes of packed values or by the run's value in byteWidth bytes.  Where a header starts
+// depends on every header before it, but following the chain one header at a time keeps a whole wave busy with scalar
+// work.  Instead the wave looks at 64 bytes of the stream at once: every lane parses the bytes at its position as if a
+// header started there (count, kind, value, position of the header after it).  Then a short scalar loop hops from the
+// chunk's first byte, which is a true header, along the lanes' "next" values and marks the lanes it visits: a few scalar
+// instructions per header.  The marked lanes hold the true segments; a wave scan of their counts gives every segment's
+// first row.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename U> __device__ __forceinline__ U wave_incl_scan(U v);
+
+struct RleCand {
+    uint32_t cnt;    // rows of the segment (clamped to 65536; `bad` when it was larger)
+    uint32_t nb;     // bytes of the header
+    uint32_t val;    // a run's value
+    uint32_t nrel;   // position of the following header, relative to the chunk's first byte (always > lane)
+    bool packed, bad;
+};
+// The header a lane sees at stream position c0 + lane; `end` is one past the stream's last byte.  [c0, c0 + 76) must be
+// in the window.
+template <class WinX>
+__device__ __forceinline__ RleCand rle_candidate(const WinX& w, uint32_t c0, uint32_t end, uint32_t bw, uint32_t bytew,
+                                                 uint32_t vmask) {
+    const uint32_t lane = threadIdx.x & 63, pos = c0 + lane;
+    const uint64_t word = w.peek64(pos);
+    const uint32_t avail = pos < end ? min(5u, end - pos) : 0u;
+    // VarInteger.readUnsignedVarInt (VarInteger.java:68-81): seven bits per byte, the first byte without the top bit ends it
+    const uint64_t term = ~word & 0x8080808080ull;
+    const uint32_t nbr = term ? ((uint32_t)__builtin_ctzll(term) >> 3) + 1u : 6u;
+    RleCand c;
+    c.nb = max(min(nbr, avail), 1u);
+    const uint32_t lo = (uint32_t)word, b4 = (uint32_t)(word >> 32) & 0x7Fu;
+    uint32_t h = (lo & 0x7Fu) | ((lo >> 1) & 0x3F80u) | ((lo >> 2) & 0x1FC000u) | ((lo >> 3) & 0xFE00000u) | (b4 << 28);
+    h &= c.nb >= 5u ? 0xFFFFFFFFu : ((1u << (7u * c.nb)) - 1u);
+    c.packed = h & 1u;
+    const uint32_t cnt = h >> 1;
+    c.bad = nbr > avail || cnt > 65536u;  // the varint runs off the stream or has no end; more rows than a pack can hold
+    c.cnt = min(cnt, 65536u);
+    c.val = (uint32_t)(word >> (8u * c.nb)) & vmask;
+    const uint32_t payload = c.packed ? ((c.cnt + 7u) >> 3) * bw : bytew;
+    c.nrel = avail ? lane + c.nb + payload : 64u + lane;
+    return c;
+}
+// Marks the lanes of the chunk that hold true headers (lane 0 does); `limit` (1..64) is the number of chunk bytes that
+// belong to the stream, `exit_rel` is where the chain leaves them.
+__device__ __forceinline__ uint64_t rle_chain(uint32_t nrel, uint32_t limit, uint32_t& exit_rel) {
+    uint64_t mask = 0;
+    uint32_t p = 0;
+    do {
+        mask |= 1ull << p;
+        p = (uint32_t)__builtin_amdgcn_readlane((int)nrel, (int)p);
+    } while (p < limit);
+    exit_rel = p;
+    return mask;
+}
+
+// Walk the id stream and record, for every tile of kRleTile rows, the segment that covers the tile's first row:
 //   x = pack offset of the segment's payload (bit-packed values), or of the byte after a run's value
 //   y = first row of the segment, z = its row count, w = 1 for bit-packed segments, (run value << 1) for runs
 __device__ int32_t walk_rle(Win& w, uint32_t off, uint32_t len, uint32_t n, uint32_t bw, uint4* restart) {
-    const int lane = threadIdx.x & 63;
+    const uint32_t lane = threadIdx.x & 63;
     off = __builtin_amdgcn_readfirstlane(off);
     len = __builtin_amdgcn_readfirstlane(len);
     n = __builtin_amdgcn_readfirstlane(n);
@@ -366,38 +420,30 @@ __device__ int32_t walk_rle(Win& w, uint32_t off, uint32_t len, uint32_t n, uint
     uint32_t pos = off + 4;
     const uint32_t end = off + 4 + len;
     const uint32_t bytew = (bw + 7) >> 3;
-    uint32_t o = 0, next_tile = 0;
-    int32_t err = 0;
     const uint32_t vmask = (1u << (8 * bytew)) - 1u;
+    uint32_t o = 0;
     while (pos < end) {
-        // this chain runs on the CU's one scalar unit: keep the common case (one-byte header) short
-        w.need(pos, 16);
-        const uint32_t first4 = w.peek32u(pos);
-        uint32_t h, val = (first4 >> 8) & vmask;  // a run's value follows a one-byte header directly
-        if (!(first4 & 0x80u)) {
-            h = first4 & 0x7Fu;
-            pos++;
-        } else {
-            h = (uint32_t)win_uvarint(w, pos, end, 5, err);
-            if (err) break;
-            val = (uint32_t)w.peek64u(pos) & vmask;  // need(pos, 16) above covers header + value
+        if (!w.has(pos, 80u)) w.load(pos);
+        const RleCand c = rle_candidate(w, pos, end, bw, bytew, vmask);
+        uint32_t exit_rel;
+        const uint64_t mask = rle_chain(c.nrel, min(64u, end - pos), exit_rel);
+        const bool mine = (mask >> lane) & 1ull;
+        const uint32_t rows = mine ? c.cnt : 0u;
+        const uint32_t inc = wave_incl_scan(rows);
+        const uint32_t first = o + inc - rows;  // < 2^23: at most 64 segments of at most 65536 rows
+        // count > valCount - valIndex would write past the output; a payload must end inside the stream
+        const bool bad = mine && (c.bad || first + rows > n || pos + c.nrel > end);
+        if (__builtin_amdgcn_ballot_w64(bad)) return E_CORRUPT;
+        if (mine && rows) {
+            const uint32_t dp = pos + lane + c.nb;
+            const uint4 rec = make_uint4(c.packed ? dp : dp + bytew, first, rows, c.packed ? 1u : (c.val << 1));
+            // tiles whose first row lies inside this segment
+            for (uint32_t t = (first + kRleTile - 1) / kRleTile; t * (uint32_t)kRleTile < first + rows; t++) restart[t] = rec;
         }
-        const uint32_t cnt = h >> 1;
-        const bool packed = h & 1;
-        if (cnt > n - o) { err = E_CORRUPT; break; }                     // also bounds the product below (cnt <= 65536)
-        const uint32_t payload = packed ? ((cnt + 7) >> 3) * bw : bytew;
-        if (pos + payload > end) { err = E_CORRUPT; break; }
-        const uint32_t t1 = (o + cnt + kRleTile - 1) / kRleTile;  // tiles [next_tile, t1) start inside this segment
-        if (cnt && next_tile < t1) {
-            const uint4 rec = make_uint4(packed ? pos : pos + bytew, o, cnt, packed ? 1u : (val << 1));
-            for (uint32_t t = next_tile + lane; t < t1; t += 64) restart[t] = rec;
-            next_tile = t1;
-        }
-        o += cnt;
-        pos += payload;
+        o += __builtin_amdgcn_readlane((int)inc, 63);
+        pos += exit_rel;
     }
-    if (!err && o != n) err = E_CORRUPT;  // Preconditions.checkState(valIndex == valCount) :126
-    return err;
+    return o != n ? E_CORRUPT : 0;  // Preconditions.checkState(valIndex == valCount) :126
 }
 
 // What a pack is, from its descriptor and fixed-position header fields: kind, dictionary geometry, where its serial
@@ -981,95 +1027,78 @@ __device__ __forceinline__ void pack_block_remap(uint32_t& bx, uint32_t& by) {
 template <class WinX>
 __device__ __forceinline__ void rle_tile_expand(WinX& w, uint32_t bw, uint32_t ids_end, uint4 seg, uint32_t tile_start,
                                                 uint32_t tile_end, uint16_t* ids) {
-    const int lane = threadIdx.x & 63;
+    const uint32_t lane = threadIdx.x & 63;
     bw = __builtin_amdgcn_readfirstlane(bw);
     ids_end = __builtin_amdgcn_readfirstlane(ids_end);
     tile_start = __builtin_amdgcn_readfirstlane(tile_start);
     tile_end = __builtin_amdgcn_readfirstlane(tile_end);
     const uint32_t bytew = (bw + 7) >> 3, vmask = (1u << (8 * bytew)) - 1u;  // bytew is 0..2
-    // the segment state is the same in every lane: keep it in scalar registers
-    uint32_t dpos = __builtin_amdgcn_readfirstlane(seg.x), o = __builtin_amdgcn_readfirstlane(seg.y);
-    uint32_t cnt = __builtin_amdgcn_readfirstlane(seg.z);
-    const uint32_t sw = __builtin_amdgcn_readfirstlane(seg.w);
-    bool packed = sw & 1u;
-    uint32_t val = sw >> 1;
-    // Columns with many short runs have ~100 segments per tile.  The chain of headers is inherently serial and runs on the
-    // CU's single scalar unit, shared by all its waves, so the walk does the minimum per segment: short segments (<= 64 rows)
-    // are only noted in a table (x: payload position or run value; y: first row in the tile | rows << 10 | rows to skip << 17 |
-    // packed << 23) and expanded afterwards with one lane per segment.  Long segments are expanded by the whole wave at once.
-    uint2* tab = (uint2*)(w.lds + WinX::kBytes + 16);
-    uint32_t nseg = 0;
-    auto flush = [&]() {
-        if (nseg == 0) return;
-        WinX::wave_lds_sync();
-        for (uint32_t s = lane; s < nseg; s += 64) {
-            const uint2 e = tab[s];
-            const uint32_t r0 = e.y & 1023u, rows = (e.y >> 10) & 127u, skip = (e.y >> 17) & 63u;
-            if ((e.y >> 23) & 1u) {
-                for (uint32_t k = 0; k < rows; k++) ids[r0 + k] = (uint16_t)w.bits(e.x, (skip + k) * bw, bw);
-            } else {
-                for (uint32_t k = 0; k < rows; k++) ids[r0 + k] = (uint16_t)e.x;
-            }
-        }
-        nseg = 0;
-        WinX::wave_lds_sync();
-    };
-    while (true) {
+    // One segment expanded by the whole wave; all arguments are the same in every lane.
+    auto expand_wide = [&](uint32_t dpos, uint32_t o, uint32_t cnt, bool packed, uint32_t val) {
         const uint32_t lo = max(o, tile_start), hi = min(o + cnt, tile_end);
-        uint32_t next = packed ? dpos + ((cnt + 7) >> 3) * bw : dpos;
-        if (lo < hi) {
-            if (cnt <= 64u) {
-                if (packed) {  // the segment's payload (<= 128 bytes) must sit in the window when the table is expanded
-                    if (!w.has(dpos, 144u)) { flush(); w.load(dpos); }
-                }
-                if (lane == 0) tab[nseg] = make_uint2(packed ? dpos : val, (lo - tile_start) | ((hi - lo) << 10) | ((lo - o) << 17) | ((uint32_t)packed << 23));
-                nseg++;
-                if (nseg == WinX::kTabN) flush();
-            } else if (packed) {
-                // bytes holding rows [lo, hi) of this segment: at most kRleTile * 16 bits; a window smaller than that takes
-                // the rows in stretches that fit (a stretch starts at most 15 bytes into the window, reads run 8 bytes over)
-                const uint32_t rows_per = (((WinX::kBytes - 48u) * 8u) / max(bw, 1u)) & ~63u;
-                for (uint32_t l2 = lo; l2 < hi; l2 += rows_per) {
-                    const uint32_t h2 = min(hi, l2 + rows_per);
-                    const uint32_t b0 = dpos + (((l2 - o) * bw) >> 3);
-                    const uint32_t b1 = dpos + (((h2 - o) * bw + 7) >> 3);
-                    if (!w.has(b0, b1 - b0 + 8)) { flush(); w.load(b0); }
+        if (lo >= hi) return;
+        if (packed) {
+            // bytes holding rows [lo, hi) of this segment: at most kRleTile * 16 bits; a window smaller than that takes
+            // the rows in stretches that fit (a stretch starts at most 15 bytes into the window, reads run 8 bytes over)
+            const uint32_t rows_per = (((WinX::kBytes - 48u) * 8u) / max(bw, 1u)) & ~63u;
+            for (uint32_t l2 = lo; l2 < hi; l2 += rows_per) {
+                const uint32_t h2 = min(hi, l2 + rows_per);
+                const uint32_t b0 = dpos + (((l2 - o) * bw) >> 3);
+                const uint32_t b1 = dpos + (((h2 - o) * bw + 7) >> 3);
+                if (!w.has(b0, b1 - b0 + 8)) w.load(b0);
 #pragma unroll 4
-                    for (uint32_t i = l2 + lane; i < h2; i += 64) ids[i - tile_start] = (uint16_t)w.bits(dpos, (i - o) * bw, bw);
-                }
-            } else {
-                for (uint32_t i = lo + lane; i < hi; i += 64) ids[i - tile_start] = (uint16_t)val;
+                for (uint32_t i = l2 + lane; i < h2; i += 64) ids[i - tile_start] = (uint16_t)w.bits(dpos, (i - o) * bw, bw);
             }
-        }
-        o += cnt;
-        if (o >= tile_end || next >= ids_end) break;
-        // next segment header: uvarint (<= 5 bytes, none at or beyond ids_end), then a run's value
-        if (!w.has(next, 16)) { flush(); w.load(next); }
-        const uint32_t first4 = w.peek32u(next);
-        if (!(first4 & 0x80u)) {  // one-byte header: the common case
-            cnt = (first4 & 0x7Fu) >> 1;
-            packed = first4 & 1u;
-            dpos = next + 1;
-            if (!packed) { val = (first4 >> 8) & vmask; dpos += bytew; }
         } else {
-            const uint64_t word = w.peek64u(next);
-            const uint32_t avail = min(5u, ids_end - next);
-            uint32_t h = 0, nb = 0;
-            bool open = true;
-#pragma unroll
-            for (uint32_t i = 0; i < 5; i++) {
-                const uint32_t b = (uint32_t)(word >> (8 * i)) & 0xFFu;
-                const bool take = open && i < avail;
-                if (take) { h |= (b & 0x7F) << (7 * i); nb = i + 1; }
-                open = take && (b & 0x80);
-            }
-            cnt = h >> 1;
-            packed = h & 1u;
-            dpos = next + nb;
-            if (!packed) { val = (uint32_t)(word >> (8 * nb)) & vmask; dpos += bytew; }
+            for (uint32_t i = lo + lane; i < hi; i += 64) ids[i - tile_start] = (uint16_t)val;
         }
+    };
+    // the segment that covers the tile's first row, as the parse kernel recorded it
+    uint32_t o, next;
+    {
+        const uint32_t dpos = __builtin_amdgcn_readfirstlane(seg.x), o0 = __builtin_amdgcn_readfirstlane(seg.y);
+        const uint32_t cnt = __builtin_amdgcn_readfirstlane(seg.z), sw = __builtin_amdgcn_readfirstlane(seg.w);
+        expand_wide(dpos, o0, cnt, sw & 1u, sw >> 1);
+        o = o0 + cnt;
+        next = (sw & 1u) ? dpos + ((cnt + 7) >> 3) * bw : dpos;
     }
-    flush();
+    // the headers after it, 64 bytes of the stream at a time (see rle_candidate): segments of up to kShort rows are
+    // expanded by the lane that holds their header, longer ones by the whole wave one after the other
+    constexpr uint32_t kShort = 32;
+    while (o < tile_end && next < ids_end) {
+        // the chunk, a header that starts at its last byte, and the payload of a short bit-packed segment behind it
+        if (!w.has(next, 64u + 8u + (kShort / 8u) * 16u + 8u)) w.load(next);
+        const RleCand c = rle_candidate(w, next, ids_end, bw, bytew, vmask);
+        uint32_t exit_rel;
+        const uint64_t mask = rle_chain(c.nrel, min(64u, ids_end - next), exit_rel);
+        const bool mine = (mask >> lane) & 1ull;
+        const uint32_t rows = mine ? c.cnt : 0u;
+        const uint32_t inc = wave_incl_scan(rows);
+        const uint32_t first = o + inc - rows;
+        const uint32_t lo = max(first, tile_start), hi = min(first + rows, tile_end);
+        const uint32_t dp = next + lane + c.nb;  // payload of a bit-packed segment
+        const bool live = lo < hi;
+        if (live && rows <= kShort) {
+            uint16_t* dst = ids + (lo - tile_start);
+            const uint32_t m = hi - lo;
+            if (c.packed) {
+                const uint32_t skip = lo - first;
+                for (uint32_t k = 0; k < m; k++) dst[k] = (uint16_t)w.bits(dp, (skip + k) * bw, bw);
+            } else {
+                for (uint32_t k = 0; k < m; k++) dst[k] = (uint16_t)c.val;
+            }
+        }
+        uint64_t wide = __builtin_amdgcn_ballot_w64(live && rows > kShort);
+        while (wide) {
+            const int l = __builtin_ctzll(wide);
+            wide &= wide - 1;
+            expand_wide((uint32_t)__builtin_amdgcn_readlane((int)dp, l), (uint32_t)__builtin_amdgcn_readlane((int)first, l),
+                        (uint32_t)__builtin_amdgcn_readlane((int)rows, l), __builtin_amdgcn_readlane((int)c.packed, l),
+                        (uint32_t)__builtin_amdgcn_readlane((int)c.val, l));
+        }
+        o += __builtin_amdgcn_readlane((int)inc, 63);
+        next += exit_rel;
+    }
     // the tile's ids were written by this wave only and are read by this wave only
     WinX::wave_lds_sync();
 }
@@ -1907,7 +1936,7 @@ __global__ __launch_bounds__(256) void k_str_copy(const DevPack* __restrict__ pa
 #endif
 // The kernel waits for gathers that miss L2, so what it needs is waves: the LDS of a wave is kept small (a 2 KB stream window
 // instead of the usual 4 KB, the row offsets of half a tile at a time) so that eight workgroups fit a compute unit.
-using FusedWin = WinT<2048, 64>;
+using FusedWin = WinT<2048>;
 constexpr uint32_t kFusedPassRows = IXR_FUSED_PASS_ROWS;
 constexpr uint32_t kFusedDltOff = (4 * (kFusedPassRows + 1) + 15) & ~15u;  // the deltas start 16-byte aligned behind the offsets
 constexpr uint32_t kFusedWaveLds =                      // per wave: stream window + id tile while expanding, then offsets[] + deltas[]
