@@ -309,6 +309,7 @@ static ixr_plan* plan_create(int32_t device, const ixr_pack_desc* descs, int32_t
         int n_str = 0;
         for (int i = 0; i < n_packs; i++) n_str += descs[i].data_type == IXR_STRING;
         if (2 * n_str >= n_packs) pl->lane_walk_from = 2048;
+        if (const char* e = getenv("IXR_LANE_WALK_FROM")) pl->lane_walk_from = atoi(e);  // A/B runs of the two framing walkers
     }
     // one allocation: [index area of all packs][bulk area of the largest group]; make the bulk offsets absolute
     index_total = align16(index_total) + 64;  // the bulk area never starts at offset 0 (k_str_copy may read 15 bytes before a dictionary)

@@ -107,6 +107,35 @@ __device__ __forceinline__ uint4 uniform_load<uint4>(const uint4* p) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// XCD-aware block relabelling for (blocks-per-pack, packs) grids.  Workgroups are dealt round-robin over the 8 XCDs by
+// linear id, which spreads the blocks of one pack -- and with them its dictionary -- over all 8 L2s.  Relabel so that all
+// blocks of a pack have linear ids that are equal mod 8: one pack, one L2.  Placement only affects speed.
+// ---------------------------------------------------------------------------------------------------------------
+// Which of its 8 packs an XCD takes changes from one group of 8 packs to the next: plans list their packs column by
+// column within a pack id, so with 4 or 8 columns a fixed slot would hand all packs of one column -- the cheap or the
+// expensive ones -- to the same one or two XCDs.
+__device__ __forceinline__ uint32_t xcd_slot(uint32_t group, uint32_t xcd) {
+    return (xcd + group + (group >> 3) + (group >> 6)) & 7u;
+}
+__device__ __forceinline__ void pack_block_remap(uint32_t& bx, uint32_t& by) {
+    const uint32_t gx = gridDim.x, count = gridDim.y;
+    const uint32_t L = blockIdx.y * gx + blockIdx.x;
+    const uint32_t full = count & ~7u;
+    if (L < full * gx) {
+        const uint32_t xcd = L & 7u, sidx = L >> 3;
+        by = (sidx / gx) * 8u + xcd_slot(sidx / gx, xcd);
+        bx = sidx % gx;
+    } else {
+        by = blockIdx.y;
+        bx = blockIdx.x;
+    }
+}
+// The same for grids of one workgroup per pack: the list position workgroup `b` of `count` takes.
+__device__ __forceinline__ uint32_t pack_slot_remap(uint32_t b, uint32_t count) {
+    return b < (count & ~7u) ? (b & ~7u) + xcd_slot(b >> 3, b & 7u) : b;
+}
+
 template <uint32_t kW>
 struct WinT {
     static constexpr uint32_t kBytes = kW;                    // bytes of the pack the window holds
@@ -781,7 +810,7 @@ __global__ __launch_bounds__(256) void k_parse(const DevPack* __restrict__ packs
     __shared__ int32_t s_werr[4];
     __shared__ int64_t s_first[2];
     const int k = threadIdx.x >> 6;  // wave = stream
-    const int pi = list[blockIdx.x];
+    const int pi = list[pack_slot_remap(blockIdx.x, gridDim.x)];
     const DevPack P = packs[pi];
     const uint8_t* base = in + P.in_off;
     const uint32_t psz = (uint32_t)P.pack_size;
@@ -828,13 +857,26 @@ __global__ __launch_bounds__(256) void k_parse(const DevPack* __restrict__ packs
 // ---------------------------------------------------------------------------------------------------------------
 // wave / workgroup scan helpers
 // ---------------------------------------------------------------------------------------------------------------
-template <typename U> __device__ __forceinline__ U wave_incl_scan(U v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        U t = __shfl_up(v, d);
-        if (lane >= d) v += t;
+// What lane (l - shift) of the same row of 16 lanes holds, or what the row's neighbour broadcasts, as a DPP operand: no trip
+// through the LDS crossbar.  Lanes without a source get 0.  All 64 lanes must be active.
+template <int kCtrl, int kRowMask, typename U>
+__device__ __forceinline__ U dpp_or_zero(U v) {
+    static_assert(sizeof(U) == 4 || sizeof(U) == 8, "32- or 64-bit values");
+    if constexpr (sizeof(U) == 4) {
+        return (U)__builtin_amdgcn_update_dpp(0, (int)v, kCtrl, kRowMask, 0xF, false);
+    } else {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, kCtrl, kRowMask, 0xF, false);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)((uint64_t)v >> 32), kCtrl, kRowMask, 0xF, false);
+        return (U)(((uint64_t)hi << 32) | lo);
     }
+}
+template <typename U> __device__ __forceinline__ U wave_incl_scan(U v) {
+    v += dpp_or_zero<0x111, 0xF>(v);  // row_shr:1
+    v += dpp_or_zero<0x112, 0xF>(v);  // row_shr:2
+    v += dpp_or_zero<0x114, 0xF>(v);  // row_shr:4
+    v += dpp_or_zero<0x118, 0xF>(v);  // row_shr:8: every row of 16 lanes is scanned
+    v += dpp_or_zero<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_or_zero<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
     return v;
 }
 
@@ -848,7 +890,7 @@ template <typename U>
 __global__ __launch_bounds__(256) void k_delta(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                const PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                uint8_t* __restrict__ out, uint8_t* __restrict__ scratch, int dict_only) {
-    const int pi = list[blockIdx.x];
+    const int pi = list[pack_slot_remap(blockIdx.x, gridDim.x)];
     const int sk = blockIdx.y;
     const DevPack P = packs[pi];
     const PackMeta& M = metas[pi];
@@ -996,25 +1038,6 @@ __global__ __launch_bounds__(256) void k_delta(const DevPack* __restrict__ packs
                 if (i0 + q < n) dst[i0 + q] = d[q] + pre;
         }
         carry += w0 + w1 + w2 + w3;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// XCD-aware block relabelling for (blocks-per-pack, packs) grids.  Workgroups are dealt round-robin over the 8 XCDs by
-// linear id, which spreads the blocks of one pack -- and with them its dictionary -- over all 8 L2s.  Relabel so that all
-// blocks of a pack have linear ids that are equal mod 8: one pack, one L2.  Placement only affects speed.
-// ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void pack_block_remap(uint32_t& bx, uint32_t& by) {
-    const uint32_t gx = gridDim.x, count = gridDim.y;
-    const uint32_t L = blockIdx.y * gx + blockIdx.x;
-    const uint32_t full = count & ~7u;
-    if (L < full * gx) {
-        const uint32_t xcd = L & 7u, sidx = L >> 3;
-        by = (sidx / gx) * 8u + xcd;
-        bx = sidx % gx;
-    } else {
-        by = blockIdx.y;
-        bx = blockIdx.x;
     }
 }
 
@@ -1275,7 +1298,7 @@ __device__ __forceinline__ uint64_t str_dict_cap(const DevPack& P, const PackMet
 __global__ __launch_bounds__(256) void k_str_dict_scan(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                        PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                        uint8_t* __restrict__ out, uint8_t* __restrict__ scratch, int dict_only) {
-    const int pi = list[blockIdx.x];
+    const int pi = list[pack_slot_remap(blockIdx.x, gridDim.x)];
     PackMeta& M = metas[pi];
     if (M.status < 0 || (M.kind != K_DICT_STR && M.kind != K_DELTA_STR)) return;
     if ((dict_only & 1) && M.kind == K_DELTA_STR) return;  // a front-coded pack's "dictionary" is its output
@@ -1486,12 +1509,14 @@ __global__ __launch_bounds__(256) void k_front_summary(const DevPack* __restrict
 __global__ __launch_bounds__(64) void k_front_combine(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                       const PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                       uint8_t* __restrict__ out, uint8_t* __restrict__ scratch, int use_ds) {
-    const int pi = list[blockIdx.y];
+    uint32_t bx, by;
+    pack_block_remap(bx, by);
+    const int pi = list[by];
     const DevPack P = packs[pi];
     FrontCtx f;
     if (!front_ctx(f, P, metas[pi], in, out, scratch, scratch, use_ds, true)) return;
     const int lane = threadIdx.x;
-    for (uint32_t col0 = blockIdx.x * 64; col0 < f.stride; col0 += gridDim.x * 64) {
+    for (uint32_t col0 = bx * 64; col0 < f.stride; col0 += gridDim.x * 64) {
         uint16_t* col = f.sum + col0 + lane;
         uint32_t state = 0;
         uint32_t b = 0;
@@ -1647,7 +1672,7 @@ __global__ __launch_bounds__(256) void k_front_decode(const DevPack* __restrict_
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_row_scan(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                   PackMeta* __restrict__ metas, uint8_t* __restrict__ out) {
-    const int pi = list[blockIdx.x];
+    const int pi = list[pack_slot_remap(blockIdx.x, gridDim.x)];
     PackMeta& M = metas[pi];
     if (M.status < 0 || M.kind != K_DICT_STR) return;
     const DevPack P = packs[pi];
@@ -1693,7 +1718,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_str_index(const DevPack* __rest
     __shared__ __align__(16) uint8_t s_win[kWaves][kWinAlloc];
     __shared__ uint32_t s_wsum[2][kWaves];
     __shared__ unsigned long long s_tot;
-    const int pi = list[blockIdx.x];
+    const int pi = list[pack_slot_remap(blockIdx.x, gridDim.x)];
     PackMeta& M = metas[pi];
     if (M.status < 0 || M.kind != K_DICT_STR) return;
     const DevPack& P = packs[pi];
