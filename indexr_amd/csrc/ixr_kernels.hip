@@ -83,7 +83,7 @@ __device__ __forceinline__ uint32_t bit_width32(uint32_t v) { return v ? 32u - (
 #ifndef IXR_FUSED_CHUNKS
 #define IXR_FUSED_CHUNKS 4      // 16-byte chunks per lane and step of k_str_fused
 #endif
-constexpr int kParseLaneThreshold = 16384;  // packs per launch from which k_parse_lanes is used (plans of mostly string packs: earlier)
+constexpr int kParseLaneThreshold = 32768;  // packs per launch from which k_parse_lanes is used (plans of mostly string packs: earlier)
 constexpr uint32_t kWin = 4096;
 constexpr uint32_t kWinAlloc = kWin + 16;  // bytes of LDS per window: data and 16 spare bytes so that 12-byte peeks never run off
 
