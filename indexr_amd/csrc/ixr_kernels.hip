@@ -1333,28 +1333,68 @@ __global__ __launch_bounds__(256) void k_str_dict_scan(const DevPack* __restrict
     const int32_t* pre = (const int32_t*)(scratch + P.s_lens);
     const int32_t* suf = pre + lens_stride(P.obj_count);
     uint32_t* sufoff = (uint32_t*)(suf + lens_stride(P.obj_count));
-    // validation pass: non-negative, prefix fits into the previous string, lengths bounded
-    uint32_t bad = 0, mx = 0;
-    for (uint32_t i = tid; i < ec; i += 256) {
-        const int32_t p = pre[i], s = suf[i];
-        const int64_t prevlen = i ? (int64_t)pre[i - 1] + suf[i - 1] : 0;
-        if (p < 0 || s < 0 || p > prevlen || (int64_t)p + s > 0x7fffffff) bad = 1;
-        else mx = max(mx, (uint32_t)(p + s));
+    // One pass over the two length lists, 1024 entries at a time, four neighbouring entries per thread: validation
+    // (non-negative, the prefix fits into the previous string, lengths bounded), the longest string, the exclusive scans of
+    // the lengths (-> dictionary offsets) and of the suffix lengths (-> suffix offsets) with running carries, and this
+    // thread's share of the exact 64-bit total.  Offsets of a list that turns out invalid are written all the same (inside
+    // the arrays' bounds) and never read: the pack's status says so.
+    __shared__ uint2 s_chunk[2][4];
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t bad = 0, mx = 0, total_len = 0, total_suf = 0;
+    uint64_t s64 = 0;
+    int buf = 0;
+    for (uint32_t c0 = 0; c0 < ec; c0 += 1024, buf ^= 1) {
+        const uint32_t i0 = c0 + 4u * tid;
+        int32_t p[4] = {0, 0, 0, 0}, sl[4] = {0, 0, 0, 0};
+        if (i0 + 3 < ec) {
+            const int4 pv = *(const int4*)(pre + i0), sv = *(const int4*)(suf + i0);
+            p[0] = pv.x; p[1] = pv.y; p[2] = pv.z; p[3] = pv.w;
+            sl[0] = sv.x; sl[1] = sv.y; sl[2] = sv.z; sl[3] = sv.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (i0 + k < ec) { p[k] = pre[i0 + k]; sl[k] = suf[i0 + k]; }
+        }
+        int64_t prevlen = (i0 && i0 < ec) ? (int64_t)pre[i0 - 1] + suf[i0 - 1] : 0;
+        uint32_t vl[4], vs[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool in = i0 + k < ec;
+            if (in && (p[k] < 0 || sl[k] < 0 || p[k] > prevlen || (int64_t)p[k] + sl[k] > 0x7fffffff)) bad = 1;
+            else if (in) mx = max(mx, (uint32_t)(p[k] + sl[k]));
+            prevlen = (int64_t)p[k] + sl[k];
+            vl[k] = in ? (uint32_t)(p[k] + sl[k]) : 0u;
+            vs[k] = in ? (uint32_t)sl[k] : 0u;
+            s64 += vl[k];
+        }
+        const uint32_t tl = vl[0] + vl[1] + vl[2] + vl[3], ts = vs[0] + vs[1] + vs[2] + vs[3];
+        const uint32_t il = wave_incl_scan<uint32_t>(tl), is = wave_incl_scan<uint32_t>(ts);
+        if (lane == 63) s_chunk[buf][wave] = make_uint2(il, is);
+        __syncthreads();  // one barrier per chunk: the next chunk writes the other half of s_chunk
+        uint32_t ol = total_len + il - tl, os = total_suf + is - ts;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const uint2 t = s_chunk[buf][w];
+            if (w < wave) { ol += t.x; os += t.y; }
+            total_len += t.x;
+            total_suf += t.y;
+        }
+        if (i0 + 3 < ec) {
+            *(uint4*)(doff + i0) = make_uint4(ol, ol + vl[0], ol + vl[0] + vl[1], ol + vl[0] + vl[1] + vl[2]);
+            *(uint4*)(sufoff + i0) = make_uint4(os, os + vs[0], os + vs[0] + vs[1], os + vs[0] + vs[1] + vs[2]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (i0 + k < ec) { doff[i0 + k] = ol; sufoff[i0 + k] = os; }
+                ol += vl[k];
+                os += vs[k];
+            }
+        }
     }
     bad = block_or(bad);
     mx = block_max(mx);
     if (bad) { if (tid == 0) M.status = E_CORRUPT; return; }
-    // the individual lengths are sane; the totals are checked against 64-bit sums below via saturating compare
-    uint32_t total_len = block_excl_scan(
-        ec, [&](uint32_t i) { return (uint32_t)(pre[i] + suf[i]); },
-        [&](uint32_t i, uint32_t ex, uint32_t) { doff[i] = ex; });
-    __syncthreads();
-    uint32_t total_suf = block_excl_scan(
-        ec, [&](uint32_t i) { return (uint32_t)suf[i]; }, [&](uint32_t i, uint32_t ex, uint32_t) { sufoff[i] = ex; });
-    // 32-bit wrap of the totals is impossible to hit without also exceeding `cap`, as long as every partial sum is
-    // checked: do it with a 64-bit reduction
-    uint64_t s64 = 0;
-    for (uint32_t i = tid; i < ec; i += 256) s64 += (uint64_t)(uint32_t)(pre[i] + suf[i]);
+    // 32-bit wrap of the totals is impossible to hit without also exceeding `cap`: the exact total is a 64-bit reduction
     __shared__ unsigned long long tot64;
     if (tid == 0) tot64 = 0;
     __syncthreads();
