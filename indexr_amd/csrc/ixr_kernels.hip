@@ -1874,6 +1874,110 @@ __global__ __launch_bounds__(kWaves * 64) void k_str_index(const DevPack* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// k_str_bases: what k_str_fused needs before it can start: the body offset of every 1024-row tile of a string dictionary
+// pack (the sum of the row lengths of the tiles before it), the checks k_str_index makes, offset[n] and the zero tail.
+// One workgroup of 16 waves per pack.  The dictionary's string lengths are first put into LDS, one byte each when no
+// string is longer than 255 bytes, else two bytes, so that a row costs an LDS read instead of a gather from global memory
+// (dictionaries whose lengths do not fit 64 KB that way keep the gathers).  A wave then takes every 16th tile on its own:
+// ids -> lengths -> one sum per tile; no barrier until all tiles are summed.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kBasesWaves = 16, kBasesTab = 65536;
+using BasesWin = WinT<2048>;
+__global__ __launch_bounds__(kBasesWaves * 64) void k_str_bases(const DevPack* __restrict__ packs, const int* __restrict__ list,
+                                                                PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
+                                                                uint8_t* __restrict__ out, uint8_t* __restrict__ scratch) {
+    __shared__ __align__(16) uint8_t s_tab[kBasesTab];
+    __shared__ __align__(16) uint8_t s_win[kBasesWaves][BasesWin::kAlloc];
+    __shared__ uint16_t s_ids[kBasesWaves][kRleTile];
+    __shared__ unsigned long long s_tile[IXR_PACK_TILES];
+    __shared__ int s_bad;
+    const int pi = list[pack_slot_remap(blockIdx.x, gridDim.x)];
+    PackMeta& M = metas[pi];
+    if (M.status < 0 || M.kind != K_DICT_STR) return;
+    const DevPack& P = packs[pi];
+    const uint32_t n = (uint32_t)P.obj_count, ec = M.entry_count;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (4ull * (n + 1) > (uint64_t)P.data_size) { if (tid == 0) M.status = E_OVERFLOW; return; }
+    const uint32_t body_cap = (uint32_t)P.data_size - 4u * (n + 1);
+    const uint32_t* __restrict__ doff = (const uint32_t*)(scratch + P.s_dict);
+    // The reference decodes the DictStruct into a buffer of the dictStructSize the pack announces and fails when it does not
+    // fit (DictCompressCodec.decode, DictCompressCodec.java:71-85; a larger buffer is accepted).  entryCount | offsets | bytes | 4n | ids
+    if (M.dict_struct_size && 4ull + 4ull * (ec + 1) + doff[ec] + 4ull + 4ull * n > (uint64_t)M.dict_struct_size) {
+        if (tid == 0) M.status = E_OVERFLOW;
+        return;
+    }
+    const uint32_t ntiles = (n + kRleTile - 1) / kRleTile;
+    if (tid == 0) s_bad = 0;
+    // ---- the length table
+    const uint32_t elem = M.max_len <= 255u ? 1u : 2u;
+    const bool tab = ec > 0 && (uint64_t)ec * elem <= kBasesTab && M.max_len <= 65535u;
+    if (tab) {
+        for (uint32_t i = tid; i < ec; i += kBasesWaves * 64) {
+            const uint32_t len = doff[i + 1] - doff[i];
+            if (elem == 1) s_tab[i] = (uint8_t)len;
+            else ((uint16_t*)s_tab)[i] = (uint16_t)len;
+        }
+    }
+    __syncthreads();
+    // ---- one sum per tile
+    const uint4* restarts = (const uint4*)(scratch + P.s_restart);
+    BasesWin w;
+    w.init(in + P.in_off, (uint32_t)P.pack_size, s_win[wave]);
+    const uint32_t id_bw = M.id_bw, ids_end = M.ids_off + 4 + M.ids_len;
+    uint16_t* ids = s_ids[wave];
+    bool bad = false;
+    for (uint32_t tile = wave; tile < ntiles; tile += kBasesWaves) {
+        const uint32_t tile_start = tile * (uint32_t)kRleTile, tile_end = min(n, tile_start + (uint32_t)kRleTile);
+        const uint32_t cnt = tile_end - tile_start;
+        BasesWin::wave_lds_sync();  // the tile before has been read
+        rle_tile_expand(w, id_bw, ids_end, restarts[tile], tile_start, tile_end, ids);
+        uint64_t sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t r = q * 256 + 4 * lane;
+            const uint2 four = ((const uint2*)ids)[q * 64 + lane];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                uint32_t id = ((g < 2 ? four.x : four.y) >> (16 * (g & 1))) & 0xFFFFu;
+                const bool in_tile = r + g < cnt;
+                if (!in_tile) id = 0;
+                if (id >= ec) { bad = true; id = 0; }
+                uint32_t len;
+                if (tab) len = elem == 1 ? (uint32_t)s_tab[id] : (uint32_t)((const uint16_t*)s_tab)[id];
+                else { uint2 ab; __builtin_memcpy(&ab, doff + id, 8); len = ab.y - ab.x; }
+                sum += in_tile ? len : 0u;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+        if (lane == 0) s_tile[tile] = sum;
+    }
+    if (bad) s_bad = 1;
+    __syncthreads();
+    if (s_bad) { if (tid == 0) M.status = E_CORRUPT; return; }
+    // ---- tile sums -> tile bases (wave 0), the exact total
+    __shared__ unsigned long long s_tot;
+    if (wave == 0) {
+        const uint64_t mine = lane < ntiles ? s_tile[lane] : 0ull;
+        const uint64_t inc = wave_incl_scan<uint64_t>(mine);
+        if (lane < ntiles) ((uint32_t*)(scratch + P.s_rows))[lane] = (uint32_t)(inc - mine);
+        if (lane == 63) s_tot = inc;
+    }
+    __syncthreads();
+    const uint64_t tot64 = s_tot;
+    if (tot64 > body_cap) {  // the body must fit dpn.dataSize = index + body (DataPackCreator_VLT.java:185-205)
+        if (tid == 0) M.status = E_OVERFLOW;
+        return;
+    }
+    uint32_t* __restrict__ off = (uint32_t*)(out + P.out_off);
+    if (tid == 0) off[n] = (uint32_t)tot64;
+    // A body shorter than dpn.dataSize promises leaves a tail: the reference decodes into a zero-filled direct buffer
+    // (PackCompressor_VLT.java:133, ByteBufferUtil.java:31-36), so the tail reads as zeros.
+    uint8_t* tail = out + P.out_off + 4ull * (n + 1) + tot64;
+    for (uint64_t i = tid; i < body_cap - tot64; i += kBasesWaves * 64) tail[i] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // k_str_copy: string dictionary packs: body[offset[i] .. offset[i+1]) = dictBody[srcOff[i] ..].  One workgroup per tile of
 // kStrTileRows rows; the tile's offsets are staged in LDS.  Each lane produces 16-byte aligned chunks of the output body:
 // a branch-free binary search in the staged offsets finds the row of the chunk's first byte, then every row that
@@ -2990,8 +3094,7 @@ void launch_str_index(const LaunchCtx& c, const int* list, int count) {
 }
 void launch_str_bases(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;
-    if (count < 1024) hipLaunchKernelGGL((k_str_index<16, true>), dim3(count), dim3(1024), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
-    else hipLaunchKernelGGL((k_str_index<4, true>), dim3(count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+    hipLaunchKernelGGL(k_str_bases, dim3(count), dim3(kBasesWaves * 64), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
 }
 void launch_str_fused(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;
