@@ -138,15 +138,17 @@ __device__ __forceinline__ uint32_t pack_slot_remap(uint32_t b, uint32_t count) 
 
 template <uint32_t kW>
 struct WinT {
-    static constexpr uint32_t kBytes = kW;                    // bytes of the pack the window holds
+    static constexpr uint32_t kBytes = kW;                    // bytes of the pack the window can hold
+    static constexpr uint32_t kLoad = kW < 4096u ? kW : 4096u; // bytes a plain load() brings in
     static constexpr uint32_t kAlloc = kW + 16;               // bytes of LDS: data, 16 spare bytes
     const uint8_t* base;  // pack start in global memory, 16-byte aligned
     uint32_t limit16;     // bytes readable from `base` in whole 16-byte chunks (pack + arena slack, rounded down)
     uint8_t* lds;         // kAlloc bytes, 16-byte aligned
-    uint32_t w0;          // pack offset held by lds[0]; the window is [w0, w0 + kW)
+    uint32_t w0;          // pack offset held by lds[0]; the window is [w0, w0 + wlen)
+    uint32_t wlen;        // bytes of the window that are loaded (kLoad after load(), up to kW after load_n())
 
     __device__ __forceinline__ void init(const uint8_t* b, uint32_t pack_size, uint8_t* l) {
-        base = b; limit16 = __builtin_amdgcn_readfirstlane((pack_size + kInSlack) & ~15u); lds = l; w0 = 0xFFFFFFFFu;
+        base = b; limit16 = __builtin_amdgcn_readfirstlane((pack_size + kInSlack) & ~15u); lds = l; w0 = 0xFFFFFFFFu; wlen = kLoad;
     }
     // LDS instructions of one wave execute in program order, so ordering window writes against window reads needs a
     // fence for the compiler only, and only over LDS (a fence that covers global memory as well can make the wave wait
@@ -159,25 +161,51 @@ struct WinT {
         const int lane = threadIdx.x & 63;
         wave_lds_sync();
         w0 = __builtin_amdgcn_readfirstlane(pos & ~15u);
+        wlen = kLoad;
         // all chunk loads are issued before the first is consumed: out-of-range chunks re-read the last valid one
         // (loading only the kilobytes a tile is expected to need was measured: 3 to 15 % slower, the chunk loads then sit
         // behind branches)
-        uint4 v[kW / 1024];
+        uint4 v[kLoad / 1024];
 #pragma unroll
-        for (uint32_t i = 0; i < kW / 1024; i++) {
+        for (uint32_t i = 0; i < kLoad / 1024; i++) {
             const uint32_t off = w0 + i * 1024 + lane * 16;  // multiple of 16, so an in-range chunk ends <= limit16
             v[i] = *(const uint4*)(base + min(off, limit16 - 16u));
             if (off >= limit16) v[i] = make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
-        for (uint32_t i = 0; i < kW / 1024; i++) *(uint4*)(lds + i * 1024 + lane * 16) = v[i];
-        if (lane == 0) *(uint4*)(lds + kW) = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = 0; i < kLoad / 1024; i++) *(uint4*)(lds + i * 1024 + lane * 16) = v[i];
+        if (lane == 0) *(uint4*)(lds + kLoad) = make_uint4(0, 0, 0, 0);
         wave_lds_sync();
     }
-    __device__ __forceinline__ bool has(uint32_t pos, uint32_t bytes) const { return pos >= w0 && pos + bytes <= w0 + kW; }
-    // make [pos, pos + bytes) part of the window (bytes <= kW - 16)
+    // a longer stretch: [pos, pos + bytes) and at least kLoad bytes, at most kW, in kilobytes; eight loads per lane in flight
+    __device__ __forceinline__ void load_n(uint32_t pos, uint32_t bytes) {
+        const int lane = threadIdx.x & 63;
+        wave_lds_sync();
+        w0 = __builtin_amdgcn_readfirstlane(pos & ~15u);
+        const uint32_t nk = __builtin_amdgcn_readfirstlane(min(kW / 1024u, max(kLoad / 1024u, (bytes + 15u + 1023u) / 1024u)));
+        wlen = nk * 1024u;
+        for (uint32_t k0 = 0; k0 < nk; k0 += 8) {
+            uint4 v[8];
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++) {
+                const uint32_t off = w0 + (k0 + i) * 1024 + lane * 16;
+                v[i] = *(const uint4*)(base + min(off, limit16 - 16u));
+                if (off >= limit16) v[i] = make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++)
+                if (k0 + i < nk) *(uint4*)(lds + (k0 + i) * 1024 + lane * 16) = v[i];
+        }
+        if (lane == 0) *(uint4*)(lds + wlen) = make_uint4(0, 0, 0, 0);
+        wave_lds_sync();
+    }
+    __device__ __forceinline__ uint32_t len() const {
+        if constexpr (kW == kLoad) return kW; else return wlen;
+    }
+    __device__ __forceinline__ bool has(uint32_t pos, uint32_t bytes) const { return pos >= w0 && pos + bytes <= w0 + len(); }
+    // make [pos, pos + bytes) part of the window (bytes <= kLoad - 16)
     __device__ __forceinline__ void need(uint32_t pos, uint32_t bytes) {
-        if (pos < w0 || pos + bytes > w0 + kW) load(pos);
+        if (pos < w0 || pos + bytes > w0 + len()) load(pos);
     }
     // The walkers below read the same address in every lane; readfirstlane tells the compiler so, which keeps the whole
     // chain (positions, widths, branches) in scalar registers and scalar branches.
@@ -222,7 +250,8 @@ using Win = WinT<kWin>;  // the window of every kernel but the fused string kern
 // VarInteger.readUnsignedVarInt / readUnsignedVarLong (VarInteger.java:68-96) out of the window: at most `max_bytes`
 // (5 or 10) bytes, none at or beyond `end`.  Returns the value, advances pos; sets err when the varint runs off the stream
 // or does not terminate.
-__device__ __forceinline__ uint64_t win_uvarint(Win& w, uint32_t& pos, uint32_t end, int max_bytes, int32_t& err) {
+template <class WinX>
+__device__ __forceinline__ uint64_t win_uvarint(WinX& w, uint32_t& pos, uint32_t end, int max_bytes, int32_t& err) {
     if (pos >= end) { err = E_CORRUPT; return 0; }
     w.need(pos, 16);
     const uint64_t lo = w.peek64u(pos);
@@ -258,11 +287,23 @@ __device__ __forceinline__ int64_t unzigzag64(uint64_t r) { return (int64_t)((r 
 // Walk one DELTA stream (DeltaCodec.decodeInts/decodeLongs framing, DeltaCodec.java:100-141, 204-245) and write its index.
 // Where a block starts depends on every width byte before it, and a single wave issues one instruction every few cycles,
 // so the serial part does the least it can: it follows the chain (length of the block's varint, four width bytes) and notes
-// each block's position and widths in LDS (`s_blk`, one uint2 per block, 64 blocks a round).  Decoding the block minimum, building the index
-// words and checking the widths then runs one block per lane.
-__device__ int32_t walk_delta(Win& w, uint32_t pack_size, uint32_t off, uint32_t n, int width, int64_t* min_delta, uint32_t* mb,
+// each block's position and widths in LDS (`s_blk`, one uint2 per block, up to 64 blocks a round).  Decoding the block
+// minimum, building the index words and checking the widths then runs one block per lane.
+//
+// Streams often keep one block size for long stretches (a column of one bit width whose block minima have varints of one
+// length).  When the last blocks of a round had equal sizes S, the next round guesses: lane l assumes that a block starts at
+// pos + l * S and parses it there, out of a longer window (up to 16 KB), all lanes at once.  Lane 0's block is real; lane
+// l's is real when every lane before it found a block of exactly S bytes.  So the round accepts the lanes up to and
+// including the first whose block has another size (that block still starts where it was assumed to) and goes on behind
+// it: up to 64 blocks for the price of one.  A guess that fails costs one parse; rounds that accept little send the walk
+// back to the serial chain until sizes repeat again.
+// The window is 16 KB where few packs are walked at a time (every stream's latency counts) and 4 KB in large launches
+// (more walkers fit a compute unit).
+using DeltaWin = WinT<16384>;
+template <class DeltaWin>
+__device__ int32_t walk_delta(DeltaWin& w, uint32_t pack_size, uint32_t off, uint32_t n, int width, int64_t* min_delta, uint32_t* mb,
                               int64_t* first_out, uint2* s_blk) {
-    const int lane = threadIdx.x & 63;
+    const uint32_t lane = threadIdx.x & 63;
     // the arguments are equal in all lanes; say so, so that the chain below stays in scalar registers
     pack_size = __builtin_amdgcn_readfirstlane(pack_size);
     off = __builtin_amdgcn_readfirstlane(off);
@@ -278,100 +319,175 @@ __device__ int32_t walk_delta(Win& w, uint32_t pack_size, uint32_t off, uint32_t
     uint64_t raw = win_uvarint(w, pos, end, (int)vb, err);
     *first_out = width == 32 ? unzigzag32(raw) : unzigzag64(raw);
     if (err) return err;
-    const uint32_t nb = (n + kBlock - 1) / kBlock;
+    const uint32_t nb = (n + kBlock - 1) / kBlock, nfull = n / kBlock;
     // a block is at most 10 + 4 * (1 + 4 * width) bytes: one window check per block, then plain LDS byte reads
     const uint32_t block_max = 10u + 4u * (1u + 4u * W) + 16u;
     bool bad = false;
-    for (uint32_t b0 = 0; b0 < nb && !err; b0 += 64) {
-    const uint32_t b1 = min(nb, b0 + 64u);
-    for (uint32_t b = b0; b < b1; b++) {
-        // the position is the same in every lane: keeping it (and everything derived from it) in scalar registers makes
-        // the loop's branches scalar branches instead of execution-mask bookkeeping
+    uint32_t guess = 0;       // block size to try next, 0: walk the chain
+    uint32_t serial_len = 16; // blocks of the next serial round: short at first, to get to a guess early
+    for (uint32_t b0 = 0; b0 < nb && !err;) {
         pos = __builtin_amdgcn_readfirstlane(pos);
-        if (pos >= end) { err = E_CORRUPT; break; }
-        w.need(pos, block_max);
-        const uint32_t start = pos;
-        // the varint's length: bytes up to the first one without the continuation bit; it must end inside the stream
-        // and within vb bytes (VarInteger.java:68-96)
-        uint32_t vl = 1;
-        if (w.u8(pos) >= 0x80u) {
-            const uint64_t lo = w.peek64u(pos);
-            const uint64_t stop = ~lo & 0x8080808080808080ull;
-            if (stop) {
-                vl = ((uint32_t)__builtin_ctzll(stop) >> 3) + 1u;
-            } else {
-                const uint32_t hi = (uint32_t)w.peek64u(pos + 8);
-                vl = !(hi & 0x80u) ? 9u : (!(hi & 0x8000u) ? 10u : 11u);
+        // ---- a round of guessed block starts
+        if (guess && b0 < nfull) {
+            const uint32_t want = min(64u, nfull - b0);
+            const uint32_t span = min(want * guess + block_max, DeltaWin::kBytes - 16u);
+            if (!w.has(pos, span)) w.load_n(pos, span);
+            // lanes whose block lies in the window if it has the guessed size (lane 0's does whatever its size: span >= block_max)
+            const uint32_t wend = w.w0 + w.len();
+            const uint32_t cover = min(want, (wend - pos - 16u) / guess);
+            const uint32_t g = pos + lane * guess;
+            const bool act = lane < cover;
+            bool ok = act && g < end;
+            const uint32_t gs = ok ? g : pos;  // lanes without a block read where lane 0 reads
+            const uint64_t lo = w.peek64(gs), hi = w.peek64(gs + 8);
+            uint64_t v = 0;
+            uint32_t used = 0;
+            bool open = true, term = false;
+            const uint32_t avail = min(vb, end - gs);
+#pragma unroll
+            for (uint32_t i = 0; i < 10; i++) {
+                const uint32_t byte = (uint32_t)((i < 8 ? lo : hi) >> (8 * (i & 7))) & 0xFFu;
+                const bool take = open && i < avail;
+                if (take) { v |= (uint64_t)(byte & 0x7Fu) << (7 * i); used = i + 1; term = !(byte & 0x80u); }
+                open = take && (byte & 0x80u);
             }
-            vl = __builtin_amdgcn_readfirstlane(vl);
-            if (vl > min(vb, end - pos)) { err = E_CORRUPT; break; }
+            ok = ok && term;
+            uint32_t p = gs + used, idx[4];
+            bool wide = false;
+#pragma unroll
+            for (uint32_t m = 0; m < 4; m++) {
+                const uint32_t bw = w.lds[min(p - w.w0, w.len() + 15u)];  // a block that runs off the window is not a covered one
+                wide |= bw > W;
+                idx[m] = (p + 1) | (bw << 24);
+                p += 1 + 4 * min(bw, W);
+            }
+            const uint32_t size = p - gs;
+            ok = ok && p <= end && p < (1u << 24);
+            // the first covered lane whose block is not a sound block of the guessed size ends the round (and is part of it)
+            const uint64_t odd = __builtin_amdgcn_ballot_w64(act && !(ok && size == guess));
+            uint32_t last = odd ? (uint32_t)__builtin_ctzll(odd) : cover - 1u;
+            // a block of another size may run off the window (lane 0's cannot): then its widths were not read from the pack;
+            // the round ends before it and the chain takes it
+            if (last > 0 && (uint32_t)__builtin_amdgcn_readlane((int)p, (int)last) + 16u > wend) {
+                last--;
+                guess = 0;
+            }
+            if (!__builtin_amdgcn_readlane((int)ok, (int)last)) { err = E_CORRUPT; break; }  // a real block start, a broken block
+            if (lane <= last) {
+                const uint32_t b = b0 + lane;
+                min_delta[b] = width == 32 ? unzigzag32(v) : unzigzag64(v);
+                bad |= wide;
+                *(uint2*)(mb + b * 4) = make_uint2(idx[0], idx[1]);  // the index words start 8-byte aligned
+                *(uint2*)(mb + b * 4 + 2) = make_uint2(idx[2], idx[3]);
+            }
+            pos = (uint32_t)__builtin_amdgcn_readlane((int)p, (int)last);
+            b0 += last + 1;
+            // a lone odd block in a long run keeps the guess; little accepted: back to the chain
+            if (last < 8u && last + 1u < cover) guess = 0;
+            serial_len = 64;
+            continue;
         }
-        pos += vl;
-        const uint32_t cnt = min((uint32_t)kBlock, n - b * kBlock);
-        uint32_t bws = 0;
-        if (cnt == (uint32_t)kBlock) {
-            // full block: four mini-blocks of 32 values, 4 * bw payload bytes each.  Positions only grow, so running off the
-            // stream (or past the 24 bits an index word holds) shows in the final position: one check per block.  Bytes
-            // read beyond the stream's end in the meantime come from the window (zero filled past the arena's slack).
-            // (Reading the candidates for all possible widths at once, to pay one trip to LDS per block instead of four, was
-            // tried: a lone wave is bound by the number of instructions it issues, and that version issues more.)
-#pragma unroll
-            for (uint32_t m = 0; m < 4; m++) {
-                const uint32_t bw = w.u8(pos);
-                bws |= bw << (8 * m);
-                pos += 1 + 4 * min(bw, W);
+        // ---- a round of the serial chain
+        const uint32_t b1 = min(nb, b0 + serial_len);
+        for (uint32_t b = b0; b < b1; b++) {
+            // the position is the same in every lane: keeping it (and everything derived from it) in scalar registers makes
+            // the loop's branches scalar branches instead of execution-mask bookkeeping
+            pos = __builtin_amdgcn_readfirstlane(pos);
+            if (pos >= end) { err = E_CORRUPT; break; }
+            w.need(pos, block_max);
+            const uint32_t start = pos;
+            // the varint's length: bytes up to the first one without the continuation bit; it must end inside the stream
+            // and within vb bytes (VarInteger.java:68-96)
+            uint32_t vl = 1;
+            if (w.u8(pos) >= 0x80u) {
+                const uint64_t lo = w.peek64u(pos);
+                const uint64_t stop = ~lo & 0x8080808080808080ull;
+                if (stop) {
+                    vl = ((uint32_t)__builtin_ctzll(stop) >> 3) + 1u;
+                } else {
+                    const uint32_t hi = (uint32_t)w.peek64u(pos + 8);
+                    vl = !(hi & 0x80u) ? 9u : (!(hi & 0x8000u) ? 10u : 11u);
+                }
+                vl = __builtin_amdgcn_readfirstlane(vl);
+                if (vl > min(vb, end - pos)) { err = E_CORRUPT; break; }
             }
-        } else {
+            pos += vl;
+            const uint32_t cnt = min((uint32_t)kBlock, n - b * kBlock);
+            uint32_t bws = 0;
+            if (cnt == (uint32_t)kBlock) {
+                // full block: four mini-blocks of 32 values, 4 * bw payload bytes each.  Positions only grow, so running off the
+                // stream (or past the 24 bits an index word holds) shows in the final position: one check per block.  Bytes
+                // read beyond the stream's end in the meantime come from the window (zero filled past the arena's slack).
+                // (Reading the candidates for all possible widths at once, to pay one trip to LDS per block instead of four, was
+                // tried: a lone wave is bound by the number of instructions it issues, and that version issues more.)
 #pragma unroll
-            for (uint32_t m = 0; m < 4; m++) {
-                if (m * kMini < cnt && !err) {
-                    const uint32_t c = min((uint32_t)kMini, cnt - m * kMini);
-                    if (pos >= end) { err = E_CORRUPT; break; }
+                for (uint32_t m = 0; m < 4; m++) {
                     const uint32_t bw = w.u8(pos);
                     bws |= bw << (8 * m);
-                    pos += 1 + ((c + 7) >> 3) * min(bw, W);
+                    pos += 1 + 4 * min(bw, W);
+                }
+            } else {
+#pragma unroll
+                for (uint32_t m = 0; m < 4; m++) {
+                    if (m * kMini < cnt && !err) {
+                        const uint32_t c = min((uint32_t)kMini, cnt - m * kMini);
+                        if (pos >= end) { err = E_CORRUPT; break; }
+                        const uint32_t bw = w.u8(pos);
+                        bws |= bw << (8 * m);
+                        pos += 1 + ((c + 7) >> 3) * min(bw, W);
+                    }
+                }
+                if (err) break;
+            }
+            if (pos > end || pos >= (1u << 24)) { err = E_CORRUPT; break; }
+            if (lane == 0) s_blk[b - b0] = make_uint2(start, bws);
+        }
+        if (err) break;
+        DeltaWin::wave_lds_sync();
+        // one block per lane: the block minimum (its varint ends inside the stream, as checked above; the 16-byte load may run
+        // into the arena's slack), the four index words, the width check
+        const uint32_t b = b0 + lane;
+        uint32_t my_size = 0;
+        if (b < b1) {
+            const uint2 rec = s_blk[lane];
+            my_size = (b + 1 < b1 ? s_blk[lane + 1].x : pos) - rec.x;
+            uint4 head;
+            __builtin_memcpy(&head, w.base + rec.x, 16);
+            const uint32_t hw[4] = {head.x, head.y, head.z, head.w};
+            uint64_t v = 0;
+            uint32_t used = 0;
+            bool open = true;
+#pragma unroll
+            for (uint32_t i = 0; i < 10; i++) {
+                const uint32_t byte = (hw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                if (open) { v |= (uint64_t)(byte & 0x7Fu) << (7 * i); used = i + 1; }
+                open = open && (byte & 0x80u);
+            }
+            const int64_t md = width == 32 ? unzigzag32(v) : unzigzag64(v);
+            const uint32_t cnt = min((uint32_t)kBlock, n - b * kBlock);
+            uint32_t p = rec.x + used;
+            min_delta[b] = md;
+#pragma unroll
+            for (uint32_t m = 0; m < 4; m++) {
+                if (m * kMini < cnt) {
+                    const uint32_t c = min((uint32_t)kMini, cnt - m * kMini);
+                    const uint32_t bw = (rec.y >> (8 * m)) & 0xFFu;
+                    bad |= bw > W;
+                    mb[b * 4 + m] = (p + 1) | (bw << 24);
+                    p += 1 + ((c + 7) >> 3) * min(bw, W);
                 }
             }
-            if (err) break;
         }
-        if (pos > end || pos >= (1u << 24)) { err = E_CORRUPT; break; }
-        if (lane == 0) s_blk[b - b0] = make_uint2(start, bws);
-    }
-    if (err) break;
-    Win::wave_lds_sync();
-    // one block per lane: the block minimum (its varint ends inside the stream, as checked above; the 16-byte load may run
-    // into the arena's slack), the four index words, the width check
-    const uint32_t b = b0 + lane;
-    if (b < b1) {
-        const uint2 rec = s_blk[lane];
-        uint4 head;
-        __builtin_memcpy(&head, w.base + rec.x, 16);
-        const uint32_t hw[4] = {head.x, head.y, head.z, head.w};
-        uint64_t v = 0;
-        uint32_t used = 0;
-        bool open = true;
-#pragma unroll
-        for (uint32_t i = 0; i < 10; i++) {
-            const uint32_t byte = (hw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-            if (open) { v |= (uint64_t)(byte & 0x7Fu) << (7 * i); used = i + 1; }
-            open = open && (byte & 0x80u);
-        }
-        const int64_t md = width == 32 ? unzigzag32(v) : unzigzag64(v);
-        const uint32_t cnt = min((uint32_t)kBlock, n - b * kBlock);
-        uint32_t p = rec.x + used;
-        min_delta[b] = md;
-#pragma unroll
-        for (uint32_t m = 0; m < 4; m++) {
-            if (m * kMini < cnt) {
-                const uint32_t c = min((uint32_t)kMini, cnt - m * kMini);
-                const uint32_t bw = (rec.y >> (8 * m)) & 0xFFu;
-                bad |= bw > W;
-                mb[b * 4 + m] = (p + 1) | (bw << 24);
-                p += 1 + ((c + 7) >> 3) * min(bw, W);
-            }
-        }
-    }
-    Win::wave_lds_sync();  // the table is read before the next round overwrites it
+        DeltaWin::wave_lds_sync();  // the table is read before the next round overwrites it
+        // guess when the round's last four blocks (or more) had one size
+        const uint32_t cnt_r = b1 - b0;
+        const uint32_t last_size = (uint32_t)__builtin_amdgcn_readlane((int)my_size, (int)(cnt_r - 1u));
+        const uint64_t same = __builtin_amdgcn_ballot_w64(lane < cnt_r && my_size == last_size);
+        const uint64_t differ = ~(same << (64u - cnt_r));
+        const uint32_t streak = differ ? (uint32_t)__builtin_clzll(differ) : 64u;  // equal sizes from the round's last block down
+        guess = (streak >= 4u && b1 < nfull) ? last_size : 0u;
+        serial_len = 64;
+        b0 = b1;
     }
     if (!err && pos != end) err = E_CORRUPT;
     if (err) return err;
@@ -802,11 +918,13 @@ __global__ __launch_bounds__(256) void k_parse_lanes(const DevPack* __restrict__
     }
 }
 
+template <class DeltaWin>
 __global__ __launch_bounds__(256) void k_parse(const DevPack* __restrict__ packs, const int* __restrict__ list, int count,
                                                PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                uint8_t* __restrict__ scratch) {
-    __shared__ __align__(16) uint8_t s_win[3][kWinAlloc];
-    __shared__ uint2 s_blk[2][64];  // per DELTA stream: position and widths of the blocks of one round
+    __shared__ __align__(16) uint8_t s_dwin[2][DeltaWin::kAlloc];  // the windows of the two DELTA walkers
+    __shared__ __align__(16) uint8_t s_rwin[kWinAlloc];            // the window of the id stream's walker
+    __shared__ uint2 s_blk[2][65];  // per DELTA stream: position and widths of the blocks of one round
     __shared__ int32_t s_werr[4];
     __shared__ int64_t s_first[2];
     const int k = threadIdx.x >> 6;  // wave = stream
@@ -829,14 +947,16 @@ __global__ __launch_bounds__(256) void k_parse(const DevPack* __restrict__ packs
     int32_t werr = 0;
     int64_t first = 0;
     if (!err && k < 3) {
-        Win w;
-        w.init(base, psz, s_win[k]);
         const StreamDesc sd = k == 0 ? m.s[0] : m.s[1];
         if (k < 2 && sd.n) {
+            DeltaWin w;
+            w.init(base, psz, s_dwin[k]);
             int64_t* md = (int64_t*)(scratch + (k == 0 ? P.s_idx[0] : P.s_idx[1]));
             uint32_t* mb = (uint32_t*)(md + (P.obj_count + kBlock - 1) / kBlock);
             werr = walk_delta(w, psz, sd.in_off, sd.n, W ? W : 32, md, mb, &first, s_blk[k]);
         } else if (k == 2 && has_ids) {
+            Win w;
+            w.init(base, psz, s_rwin);
             werr = walk_rle(w, m.ids_off, m.ids_len, n, m.id_bw, (uint4*)(scratch + P.s_restart));
         }
     }
@@ -3035,8 +3155,10 @@ void launch_parse(const LaunchCtx& c, const int* list, int count) {
                            c.in, c.scratch);
         return;
     }
-    hipLaunchKernelGGL(k_parse, dim3((unsigned)count), dim3(256), 0, c.stream, c.packs, list, count, c.metas,
-                       c.in, c.scratch);
+    if (count < 1024)
+        hipLaunchKernelGGL(k_parse<DeltaWin>, dim3((unsigned)count), dim3(256), 0, c.stream, c.packs, list, count, c.metas, c.in, c.scratch);
+    else
+        hipLaunchKernelGGL(k_parse<Win>, dim3((unsigned)count), dim3(256), 0, c.stream, c.packs, list, count, c.metas, c.in, c.scratch);
 }
 void launch_delta(const LaunchCtx& c, const int* list, int count, int width, int streams) {
     if (count <= 0) return;
