@@ -5,6 +5,7 @@ The inputs restate the reference's own tests: DataPackTest literal inputs, Delta
 RLEPackingHybridCodecTest random runs, DictCodecTest cardinality sweeps over all five types, plus edge cases (tails < 8,
 every bit width, wrap-around, empty strings, maximum pack size, corrupted streams).
 """
+import os
 import struct
 
 import numpy as np
@@ -328,7 +329,7 @@ def test_corrupted_packs_fail_cleanly():
 
 
 def test_lane_walk_agrees_with_window_walk_on_corrupted_packs():
-    """Batches of 16384 packs and more take the lane-per-stream framing walk.  Mutated packs (flips anywhere in the first
+    """Large batches (32768 packs and more) take the lane-per-stream framing walk.  Mutated packs (flips anywhere in the first
     kilobyte: stream lengths, varints, mini-block width bytes, segment headers) must get the same status and the same
     bytes from it as from the window walk of a small batch."""
     r = rng(91)
@@ -351,9 +352,13 @@ def test_lane_walk_agrees_with_window_walk_on_corrupted_packs():
     outs_a, status_a, plan = run_batch(cases)
     plan.destroy()
     filler = base[0]
-    big = cases + [filler] * (16384 - len(cases) + 8)
-    outs_b, status_b, plan = run_batch(big)
-    plan.destroy()
+    big = cases + [filler] * 2000
+    os.environ["IXR_LANE_WALK_FROM"] = "1"  # read when a plan is created: this plan takes the lane walker whatever its size
+    try:
+        outs_b, status_b, plan = run_batch(big)
+        plan.destroy()
+    finally:
+        os.environ.pop("IXR_LANE_WALK_FROM", None)
     assert len({int(x) for x in status_a}) > 3  # clean packs and more than one kind of failure
     for i, c in enumerate(cases):
         assert status_a[i] == status_b[i], (c.name, status_a[i], status_b[i])
