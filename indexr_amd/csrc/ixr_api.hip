@@ -448,7 +448,7 @@ static int32_t run_group_rows(ixr_plan* pl, Timer& T, Timer& TB, LaunchCtx& c, L
     TN.run("k_copy_raw", g.cnt[L_RAW], [&] { launch_copy_raw(cn, L + g.off[L_RAW], g.cnt[L_RAW]); });
     run_group_front_str(pl, T, c, g, 0);
     if (pl->fused_str) {
-        T.run("k_str_index", g.cnt[L_STR], [&] { launch_str_bases(c, L + g.off[L_STR], g.cnt[L_STR]); });
+        T.run("k_str_bases", g.cnt[L_STR], [&] { launch_str_bases(c, L + g.off[L_STR], g.cnt[L_STR]); });
         T.run("k_str_fused", g.cnt[L_STR], [&] { launch_str_fused(c, L + g.off[L_STR], g.cnt[L_STR]); });
     } else {
         T.run("k_str_index", g.cnt[L_STR], [&] { launch_str_index(c, L + g.off[L_STR], g.cnt[L_STR]); });

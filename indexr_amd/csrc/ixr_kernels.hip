@@ -18,7 +18,8 @@
 //                1024-row tile the RLE segment covering its first row.
 //   k_delta      one workgroup per DELTA stream: bit-unpack + wave/workgroup prefix sum with a running carry.
 //   k_dict_num   one wave per 1024-row tile: expand ids from the tile's segment record, gather dictionary entries, store rows.
-//   string packs k_str_dict_scan -> k_front_decode -> k_str_index -> k_str_copy  (see each kernel)
+//   string packs k_str_dict_scan -> k_front_decode -> k_str_bases -> k_str_fused  (see each kernel; k_str_index -> k_str_copy
+//                is the two-kernel form of the last two)
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <stdint.h>
@@ -1870,7 +1871,7 @@ __global__ __launch_bounds__(256) void k_row_scan(const DevPack* __restrict__ pa
 // StringsStruct.Builder, StringsStruct.java:120-158) and each row's slice start into scratch, checks that the body fits,
 // zero-fills what the body leaves of dpn.dataSize.  (DictStruct.decodeStrings, DictStruct.java:97-110.)
 // ---------------------------------------------------------------------------------------------------------------
-template <int kWaves, bool kBasesOnly>
+template <int kWaves>
 __global__ __launch_bounds__(kWaves * 64) void k_str_index(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                     PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ scratch) {
@@ -1956,10 +1957,6 @@ __global__ __launch_bounds__(kWaves * 64) void k_str_index(const DevPack* __rest
             total += v;
         }
         const uint32_t o0 = carry + before;
-        if constexpr (kBasesOnly) {
-            // k_str_fused redoes the per-row work where the rows are copied: all it needs from here is where the tile starts
-            if (lane == 0 && cnt) srcoff[tile] = o0;
-        } else
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const uint32_t r = q * 256 + 4 * lane;
@@ -2210,7 +2207,7 @@ __global__ __launch_bounds__(256) void k_str_copy(const DevPack* __restrict__ pa
 // ---------------------------------------------------------------------------------------------------------------
 // k_str_fused: row index and body copy of string dictionary packs in one kernel, one WAVE per tile of kRleTile rows; no
 // workgroup barrier anywhere.  The wave expands its tile's ids, looks the rows' dictionary slices up, scans the row lengths
-// (the tile's first offset comes from k_str_index<.., true>, which leaves one word per tile instead of eight bytes per
+// (the tile's first offset comes from k_str_bases, which leaves one word per tile instead of eight bytes per
 // row; having every tile publish its byte count and look back at the tiles before it instead was measured: the round trips
 // of the device-scope atomics under a saturated store stream cost three times what the small kernel does),
 // writes the tile's part of the output index and keeps the rows' offsets in LDS; then it produces the tile's stretch
@@ -3211,8 +3208,8 @@ void launch_str_index(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;
     // few packs: 16 waves each shorten the one pack's chain of rounds; many packs: workgroups of 4 waves, which find room on
     // a compute unit beside the numeric kernels of the other stream
-    if (count < 1024) hipLaunchKernelGGL((k_str_index<16, false>), dim3(count), dim3(1024), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
-    else hipLaunchKernelGGL((k_str_index<4, false>), dim3(count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+    if (count < 1024) hipLaunchKernelGGL((k_str_index<16>), dim3(count), dim3(1024), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+    else hipLaunchKernelGGL((k_str_index<4>), dim3(count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
 }
 void launch_str_bases(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;
