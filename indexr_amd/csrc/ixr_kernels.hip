@@ -1002,13 +1002,14 @@ template <typename U> __device__ __forceinline__ U wave_incl_scan(U v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_delta: one 256-thread workgroup per DELTA stream.  Each thread unpacks 4 consecutive values (same mini-block) per
-// iteration; a thread-local sum, a wave scan and a 4-entry LDS combine give the running values; the carry travels in a
-// register.  Replaces the two passes of DeltaCodec.decodeIntsBlock / decodeLongsBlock (DeltaCodec.java:112-127, 216-231).
+// k_delta: one workgroup per DELTA stream, 256 threads in large launches and 1024 in small ones (a stream is a chain of
+// dependent iterations: with few streams in flight the chain is what the launch waits for, and four times the threads make it
+// a quarter as long).  Each thread unpacks 4 or 8 consecutive values (same mini-block) per iteration; a thread-local sum, a wave
+// scan and an LDS combine of the waves' totals give the running values; the carry travels in a register.  Replaces the two passes of DeltaCodec.decodeIntsBlock / decodeLongsBlock (DeltaCodec.java:112-127, 216-231).
 // Also copies plain (uncompressed) dictionary entries into the aligned scratch dictionary (PlainCodec.java:48-70).
 // ---------------------------------------------------------------------------------------------------------------
-template <typename U>
-__global__ __launch_bounds__(256) void k_delta(const DevPack* __restrict__ packs, const int* __restrict__ list,
+template <typename U, int kThreads>
+__global__ __launch_bounds__(kThreads) void k_delta(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                const PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                uint8_t* __restrict__ out, uint8_t* __restrict__ scratch, int dict_only) {
     const int pi = list[pack_slot_remap(blockIdx.x, gridDim.x)];
@@ -1027,9 +1028,9 @@ __global__ __launch_bounds__(256) void k_delta(const DevPack* __restrict__ packs
         const uint8_t* src = base + M.entries_off;
         uint8_t* dst = scratch + P.s_dict;
         if (((uintptr_t)src & 3) == 0) {
-            for (uint32_t i = tid; i < bytes / 4; i += 256) ((uint32_t*)dst)[i] = ((const uint32_t*)src)[i];
+            for (uint32_t i = tid; i < bytes / 4; i += kThreads) ((uint32_t*)dst)[i] = ((const uint32_t*)src)[i];
         } else {
-            for (uint32_t i = tid; i < bytes; i += 256) dst[i] = src[i];
+            for (uint32_t i = tid; i < bytes; i += kThreads) dst[i] = src[i];
         }
         return;
     }
@@ -1048,9 +1049,10 @@ __global__ __launch_bounds__(256) void k_delta(const DevPack* __restrict__ packs
     // consecutive values per thread (one mini-block header serves all of them): 8 pays for 32-bit values, 64-bit values
     // are faster with 4 (three dword loads per extraction already)
     constexpr int V = sizeof(U) == 4 ? 8 : 4;
-    constexpr uint32_t kChunk = 256 * V;  // values per workgroup iteration
-    __shared__ U wsum[2][4];
-    __shared__ uint32_t s_win[12][256];  // per thread: the up to 48 bytes its V values are packed in, dword k at [k][tid]
+    constexpr uint32_t kChunk = kThreads * V;  // values per workgroup iteration
+    constexpr int kWaves = kThreads / 64;
+    __shared__ U wsum[2][kWaves];
+    __shared__ uint32_t s_win[12][kThreads];  // per thread: the up to 48 bytes its V values are packed in, dword k at [k][tid]
     U carry = (U)s.first;
     int buf = 0;
     // A chunk's values take two dependent round trips (the mini-block index, then the packed bits) and the workgroup
@@ -1138,11 +1140,13 @@ __global__ __launch_bounds__(256) void k_delta(const DevPack* __restrict__ packs
         const U incl = wave_incl_scan<U>(d[V - 1]);
         if (lane == 63) wsum[buf][wave] = incl;
         __syncthreads();
-        const U w0 = wsum[buf][0], w1 = wsum[buf][1], w2 = wsum[buf][2], w3 = wsum[buf][3];
-        U wprefix = 0;
-        if (wave > 0) wprefix += w0;
-        if (wave > 1) wprefix += w1;
-        if (wave > 2) wprefix += w2;
+        U wprefix = 0, wtotal = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; w++) {
+            const U t = wsum[buf][w];
+            if (w < wave) wprefix += t;
+            wtotal += t;
+        }
         const U pre = carry + wprefix + (incl - d[V - 1]);
         if (i0 + V - 1 < n) {
             if constexpr (sizeof(U) == 4) {
@@ -1158,7 +1162,7 @@ __global__ __launch_bounds__(256) void k_delta(const DevPack* __restrict__ packs
             for (int q = 0; q < V; q++)
                 if (i0 + q < n) dst[i0 + q] = d[q] + pre;
         }
-        carry += w0 + w1 + w2 + w3;
+        carry += wtotal;
     }
 }
 
@@ -3159,12 +3163,14 @@ void launch_parse(const LaunchCtx& c, const int* list, int count) {
 }
 void launch_delta(const LaunchCtx& c, const int* list, int count, int width, int streams) {
     if (count <= 0) return;
-    if (width == 64)
-        hipLaunchKernelGGL(k_delta<uint64_t>, dim3(count, streams), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out,
-                           c.scratch, c.dict_only);
-    else
-        hipLaunchKernelGGL(k_delta<uint32_t>, dim3(count, streams), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out,
-                           c.scratch, c.dict_only);
+    const bool few = (long)count * streams < 512;  // fewer streams than two per compute unit: long workgroups, short chains
+    if (width == 64) {
+        if (few) hipLaunchKernelGGL((k_delta<uint64_t, 1024>), dim3(count, streams), dim3(1024), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch, c.dict_only);
+        else hipLaunchKernelGGL((k_delta<uint64_t, 256>), dim3(count, streams), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch, c.dict_only);
+    } else {
+        if (few) hipLaunchKernelGGL((k_delta<uint32_t, 1024>), dim3(count, streams), dim3(1024), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch, c.dict_only);
+        else hipLaunchKernelGGL((k_delta<uint32_t, 256>), dim3(count, streams), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch, c.dict_only);
+    }
 }
 void launch_dict_num(const LaunchCtx& c, const int* list, int count, int width) {
     if (count <= 0) return;
