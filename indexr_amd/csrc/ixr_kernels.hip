@@ -1226,14 +1226,29 @@ __device__ __forceinline__ void rle_tile_expand(WinX& w, uint32_t bw, uint32_t i
         const uint32_t lo = max(first, tile_start), hi = min(first + rows, tile_end);
         const uint32_t dp = next + lane + c.nb;  // payload of a bit-packed segment
         const bool live = lo < hi;
-        if (live && rows <= kShort) {
-            uint16_t* dst = ids + (lo - tile_start);
-            const uint32_t m = hi - lo;
-            if (c.packed) {
-                const uint32_t skip = lo - first;
-                for (uint32_t k = 0; k < m; k++) dst[k] = (uint16_t)w.bits(dp, (skip + k) * bw, bw);
-            } else {
-                for (uint32_t k = 0; k < m; k++) dst[k] = (uint16_t)c.val;
+        // The short segments' rows, one row per lane and pass: the rows are numbered through (a second scan), a row finds
+        // the lane that holds its segment by a binary search over the lanes' running totals (six lane reads), fetches what
+        // it needs of the segment from that lane and writes its id.  (One lane per segment writing its rows one after the
+        // other was measured first: the wave then takes as many steps as the chunk's longest segment has rows.)
+        const uint32_t srows = (live && rows <= kShort) ? hi - lo : 0u;
+        const uint32_t sinc = wave_incl_scan(srows);
+        const uint32_t stotal = (uint32_t)__builtin_amdgcn_readlane((int)sinc, 63);
+        if (stotal) {
+            const uint32_t sfirst = sinc - srows;
+            const uint32_t meta = (lo - tile_start) | ((lo - first) << 10) | ((uint32_t)c.packed << 16);  // row in the tile, rows skipped (< 32)
+            const uint32_t what = c.packed ? dp : c.val;
+            for (uint32_t j0 = 0; j0 < stotal; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                uint32_t own = 0;  // number of lanes whose running total is <= j: the lane of the segment row j belongs to
+#pragma unroll
+                for (uint32_t step = 32; step >= 1; step >>= 1)
+                    if ((uint32_t)__shfl((int)sinc, (int)(own + step - 1u)) <= j) own += step;
+                const uint32_t k = j - (uint32_t)__shfl((int)sfirst, (int)own);
+                const uint32_t m = (uint32_t)__shfl((int)meta, (int)own), x = (uint32_t)__shfl((int)what, (int)own);
+                if (j < stotal) {
+                    const uint32_t id = (m >> 16) ? w.bits(x, (((m >> 10) & 63u) + k) * bw, bw) : x;
+                    ids[(m & 1023u) + k] = (uint16_t)id;
+                }
             }
         }
         uint64_t wide = __builtin_amdgcn_ballot_w64(live && rows > kShort);
