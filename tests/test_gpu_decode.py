@@ -370,8 +370,9 @@ def test_lane_walk_agrees_with_window_walk_on_corrupted_packs():
 
 
 def test_string_packs_of_mixed_dictionary_sizes_in_a_large_launch():
-    """From 1024 string packs on, the index kernel runs in workgroups of 4 waves instead of 16.  Dictionaries from 40 to 30000
-    entries side by side in one such launch."""
+    """String packs with dictionaries from 40 to 30000 entries side by side in one launch of more than 1024 packs (the tile
+    bases come from a table of string lengths in LDS, whatever the dictionary's size; the two-kernel form of the string rows
+    switches from workgroups of 16 waves to 4 at that launch size)."""
     r = rng(5)
 
     def uniq(m, n):
