@@ -1796,6 +1796,59 @@ __device__ __forceinline__ void front_rounds(const FrontCtx& f, const uint4* min
     }
 }
 
+// The same for 128 byte columns at a time with EIGHT columns per lane (one 8-byte load and one 8-byte store per lane and
+// string instead of two of four bytes each): lists whose strings are longer than 64 bytes take their columns in such rounds.
+__device__ __forceinline__ uint64_t byte_mask64(uint32_t x) { return x >= 8 ? ~0ull : ((1ull << (8 * x)) - 1ull); }
+__device__ __forceinline__ void front_rounds64(const FrontCtx& f, const uint4* mine, uint32_t b, uint32_t col0, int c, uint32_t block_end,
+                                               bool whole_tails) {
+    constexpr int kB = IXR_FRONT_BATCH;
+    const uint32_t j0 = col0 + 8 * c;
+    uint64_t cur = 0;
+    if (b < f.nblk) {  // the columns' bytes before the block (one uint16 each)
+        const uint4 st = *(const uint4*)(f.sum + (size_t)b * f.stride + j0);
+        const uint32_t lo = (st.x & 0xFFu) | ((st.x >> 8) & 0xFF00u) | ((st.y & 0xFFu) << 16) | ((st.y << 8) & 0xFF000000u);
+        const uint32_t hi = (st.z & 0xFFu) | ((st.z >> 8) & 0xFF00u) | ((st.w & 0xFFu) << 16) | ((st.w << 8) & 0xFF000000u);
+        cur = (uint64_t)lo | ((uint64_t)hi << 32);
+    }
+    for (uint32_t k0 = 0; k0 < (uint32_t)kFrontBlock; k0 += kB) {
+        uint4 m[kB];
+        bool reach = false;
+#pragma unroll
+        for (int q = 0; q < kB; q++) {
+            m[q] = mine[k0 + q];
+            reach |= m[q].y > j0;
+        }
+        if (!__any(reach)) continue;  // strings that end before these columns neither read nor write here
+        uint64_t t[kB];
+#pragma unroll
+        for (int q = 0; q < kB; q++) {
+            // unconditional, clamped load (see front_rounds); may start up to 7 bytes before the suffix bytes: pack header
+            const bool fresh = j0 + 8 > m[q].x && j0 < m[q].y;
+            const int32_t at = (int32_t)(m[q].w + (fresh ? j0 : m[q].x));
+            __builtin_memcpy(&t[q], f.sfx + at, 8);
+        }
+        asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+        static_assert(kB == 8, "the loads of a batch are kept together eight at a time");
+#pragma unroll
+        for (int q = 0; q < kB; q++) {  // string by string, so that a string's tail is stored before anything of the next one
+            const uint32_t p = m[q].x, len = m[q].y;
+            const uint32_t lo = p > j0 ? min(p - j0, 8u) : 0u, hi = len > j0 ? min(len - j0, 8u) : 0u;
+            const uint64_t take = byte_mask64(hi) & ~byte_mask64(lo);  // columns inside the suffix
+            cur = (cur & ~take) | (t[q] & take);
+            const uint32_t at = m[q].z + j0;
+            uint8_t* dst = f.body + at;
+            if (hi == 8 || (hi && kFrontWholeTails && whole_tails && at + 8 <= block_end)) __builtin_memcpy(dst, &cur, 8);
+            else if (hi) {
+                uint32_t w = (uint32_t)cur, r = hi;
+                if (hi >= 4) { __builtin_memcpy(dst, &w, 4); dst += 4; w = (uint32_t)(cur >> 32); r = hi - 4; }
+                if (r > 0) dst[0] = (uint8_t)w;
+                if (r > 1) dst[1] = (uint8_t)(w >> 8);
+                if (r > 2) dst[2] = (uint8_t)(w >> 16);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_front_decode(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                       const PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                       uint8_t* __restrict__ out, uint8_t* __restrict__ scratch,
@@ -1839,7 +1892,11 @@ __global__ __launch_bounds__(256) void k_front_decode(const DevPack* __restrict_
         // two rounds of 64 columns at a time where there are that many (a lane owns dword c of both): their loads are in
         // flight together and the strings' records are read once for both
         for (uint32_t col0 = 0; col0 < f.stride; col0 += 128) {
+#ifdef IXR_FRONT_DWORD_PAIRS
             if (col0 + 64 < f.stride) front_rounds<2>(f, mine, b, col0, c, block_end, col0 == 0 && f.stride <= 128);  // wave-uniform
+#else
+            if (col0 + 64 < f.stride) front_rounds64(f, mine, b, col0, c, block_end, col0 == 0 && f.stride <= 128);  // wave-uniform
+#endif
             else front_rounds<1>(f, mine, b, col0, c, block_end, col0 == 0);
         }
     }
