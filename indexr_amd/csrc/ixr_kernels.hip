@@ -2189,6 +2189,17 @@ __device__ __forceinline__ void st16_stream(uint8_t* p, uint4 w) {
     u32x4 t = {w.x, w.y, w.z, w.w};
     __builtin_nontemporal_store(t, (u32x4*)p);
 }
+// Bytes [from, from + n) of the 16-byte value w to p, n = 1..15: the value is shifted down by `from` bytes and goes out as the
+// 8-, 4-, 2- and 1-byte pieces of n (unaligned stores), four store instructions at most instead of one per byte.
+__device__ __forceinline__ void st_part(uint8_t* p, uint4 w, uint32_t from, uint32_t n) {
+    uint64_t lo = (uint64_t)w.x | ((uint64_t)w.y << 32), hi = (uint64_t)w.z | ((uint64_t)w.w << 32);
+    if (from >= 8) { lo = hi; hi = 0; from -= 8; }
+    if (from) { lo = (lo >> (8 * from)) | (hi << (64 - 8 * from)); hi >>= 8 * from; }
+    if (n & 8) { __builtin_memcpy(p, &lo, 8); p += 8; lo = hi; }
+    if (n & 4) { const uint32_t v = (uint32_t)lo; __builtin_memcpy(p, &v, 4); p += 4; lo >>= 32; }
+    if (n & 2) { const uint16_t v = (uint16_t)lo; __builtin_memcpy(p, &v, 2); p += 2; lo >>= 16; }
+    if (n & 1) *p = (uint8_t)lo;
+}
 // 64-bit mask with the low 8*x bits set, x clamped to 0..8
 __device__ __forceinline__ uint64_t low_bytes(int x) {
     x = max(x, 0);
@@ -2422,12 +2433,7 @@ __global__ __launch_bounds__(256, IXR_FUSED_WAVES_PER_SIMD) void k_str_fused(con
             if (first == cpos && cend == cpos + 16u) {
                 st16_stream(base16 + cpos, w);
             } else {  // the first and the last chunk of a pass are shared with the neighbouring pass or tile
-                const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const uint32_t q = cpos + k;
-                    if (q >= first && q < cend) base16[q] = (uint8_t)(wv[k >> 2] >> (8 * (k & 3)));
-                }
+                st_part(base16 + first, w, first - cpos, cend - first);
             }
         };
 
