@@ -1287,6 +1287,14 @@ __device__ __forceinline__ bool tile_ctx(TileCtx& t, const DevPack* packs, const
     return true;
 }
 
+// Dictionaries of 2 to 64 KB are looked up in LDS (k_dict_lds).  Smaller ones stay in the vector L1 anyway and their packs
+// -- few distinct values, often run-heavy id streams whose expansion is the work -- are better off with the smaller
+// workgroups of k_dict_num (measured: 16 values in runs lose a third in the LDS kernel); larger ones do not fit.
+constexpr uint32_t kDictLdsBytes = 65536, kDictLdsMinBytes = 2048;
+template <typename U> __device__ __forceinline__ bool dict_in_lds(uint32_t entry_count) {
+    const uint32_t bytes = entry_count * (uint32_t)sizeof(U);
+    return bytes >= kDictLdsMinBytes && bytes <= kDictLdsBytes;
+}
 // ---------------------------------------------------------------------------------------------------------------
 // k_dict_num: numeric dictionary packs.  One wave per tile of kRleTile rows: out[i] = dict[id[i]]
 // (DictStruct.decodeInts/Longs/Floats/Doubles, indexr-common/.../data/DictStruct.java:57-95).
@@ -1299,6 +1307,7 @@ __global__ __launch_bounds__(256) void k_dict_num(const DevPack* __restrict__ pa
     __shared__ __align__(16) uint8_t s_win[4][kWinAlloc];
     TileCtx t;
     if (!tile_ctx(t, packs, list, metas, K_DICT_NUM, 0)) return;
+    if (dict_in_lds<U>(t.ec)) return;  // k_dict_lds takes this pack
     const DevPack& P = packs[t.pi];
     const PackMeta& M = metas[t.pi];
     const U* __restrict__ dict = (const U*)(scratch + P.s_dict);
@@ -1343,6 +1352,72 @@ __global__ __launch_bounds__(256) void k_dict_num(const DevPack* __restrict__ pa
         else if (r < cnt) dst[r] = v[2 * q];
     }
     if (bad) metas[t.pi].status = E_CORRUPT;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_dict_lds: numeric dictionary packs whose dictionary fits 48 KB.  A kernel that gathers from memory and stores runs at the
+// speed of a copy, however well the gathers hit the caches: loads and stores share the vector memory path.  Lookups out of
+// LDS leave that path to the id windows and the stores.  One workgroup of 16 waves per pack: the dictionary is copied
+// to LDS once (coalesced), then every wave takes every 16th tile: expands its ids and looks its rows up there.
+// (DictStruct.decodeInts/Longs/Floats/Doubles, indexr-common/.../data/DictStruct.java:57-95.)
+// ---------------------------------------------------------------------------------------------------------------
+using SmallWin = WinT<2048>;
+template <typename U>
+__global__ __launch_bounds__(1024) void k_dict_lds(const DevPack* __restrict__ packs, const int* __restrict__ list,
+                                                   PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
+                                                   uint8_t* __restrict__ out, const uint8_t* __restrict__ scratch) {
+    __shared__ __align__(16) uint8_t s_dict[kDictLdsBytes];
+    __shared__ uint16_t s_ids[16][kRleTile];
+    __shared__ __align__(16) uint8_t s_win[16][SmallWin::kAlloc];
+    const int pi = list[pack_slot_remap(blockIdx.x, gridDim.x)];
+    const PackMeta& M = metas[pi];
+    if (M.status < 0 || M.kind != K_DICT_NUM) return;
+    const uint32_t ec = M.entry_count;
+    if (!dict_in_lds<U>(ec)) return;  // k_dict_num takes this pack
+    const DevPack& P = packs[pi];
+    const uint32_t n = (uint32_t)P.obj_count, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {   // the dictionary: 16-byte pieces (the scratch dictionary starts 16-byte aligned and has 16 spare bytes behind it)
+        const uint4* src = (const uint4*)(scratch + P.s_dict);
+        const uint32_t pieces = (ec * (uint32_t)sizeof(U) + 15u) / 16u;
+        for (uint32_t i = tid; i < pieces; i += 1024) ((uint4*)s_dict)[i] = src[i];
+    }
+    __syncthreads();
+    const U* dict = (const U*)s_dict;
+    uint16_t* ids = s_ids[wave];
+    SmallWin w;
+    w.init(in + P.in_off, (uint32_t)P.pack_size, s_win[wave]);
+    bool bad = false;
+    // the pack's tiles, 16 at a time; a wave's tiles are its own business from here on (no barrier)
+    for (uint32_t tile = wave; tile * (uint32_t)kRleTile < n; tile += 16) {
+        const uint32_t tile_start = tile * (uint32_t)kRleTile;
+        const uint32_t tile_end = min(n, tile_start + (uint32_t)kRleTile), cnt = tile_end - tile_start;
+        U* __restrict__ dst = (U*)(out + P.out_off) + tile_start;
+        const uint4 seg = ((const uint4*)(scratch + P.s_restart))[tile];
+        SmallWin::wave_lds_sync();  // the tile before has been read
+        rle_tile_expand(w, M.id_bw, M.ids_off + 4 + M.ids_len, seg, tile_start, tile_end, ids);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t r = q * 128 + 2 * lane;
+            const uint32_t two = ((const uint32_t*)ids)[q * 64 + lane];
+            uint32_t i0 = r < cnt ? (two & 0xFFFFu) : 0u, i1 = r + 1 < cnt ? (two >> 16) : 0u;
+            if (i0 >= ec) { bad = true; i0 = 0; }
+            if (i1 >= ec) { bad = true; i1 = 0; }
+            const U v0 = dict[i0], v1 = dict[i1];
+            // streaming (non-temporal) stores: the rows are not read again here
+            if (r + 1 < cnt) {
+                if constexpr (sizeof(U) == 4) {
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    u32x2 t = {(uint32_t)v0, (uint32_t)v1};
+                    __builtin_nontemporal_store(t, (u32x2*)(dst + r));
+                } else {
+                    typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+                    u64x2 t = {(uint64_t)v0, (uint64_t)v1};
+                    __builtin_nontemporal_store(t, (u64x2*)(dst + r));
+                }
+            } else if (r < cnt) dst[r] = v0;
+        }
+    }
+    if (bad) metas[pi].status = E_CORRUPT;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -3253,12 +3328,16 @@ void launch_delta(const LaunchCtx& c, const int* list, int count, int width, int
 void launch_dict_num(const LaunchCtx& c, const int* list, int count, int width) {
     if (count <= 0) return;
     const unsigned gx = IXR_PACK_TILES / 4;
-    if (width == 64)
+    // every pack is taken by exactly one of the two kernels: by the size of its dictionary
+    if (width == 64) {
+        hipLaunchKernelGGL(k_dict_lds<uint64_t>, dim3(count), dim3(1024), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
         hipLaunchKernelGGL(k_dict_num<uint64_t>, dim3(gx, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out,
                            c.scratch);
-    else
+    } else {
+        hipLaunchKernelGGL(k_dict_lds<uint32_t>, dim3(count), dim3(1024), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
         hipLaunchKernelGGL(k_dict_num<uint32_t>, dim3(gx, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out,
                            c.scratch);
+    }
 }
 void launch_copy_raw(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;

@@ -244,3 +244,22 @@ def test_string_dictionaries_of_many_sizes_and_long_entries():
     pack_of(words(500, longest=70000), 2000, "an entry longer than 65535 bytes")
     pack_of(words(2000), 65536, "plain dictionary", et=O.SIMPLE_DICT)
     three_ways(cases)
+
+
+def test_numeric_dictionaries_around_the_lds_limits():
+    """Numeric dictionaries of 2 to 64 KB are looked up in LDS by a kernel of their own: entry counts either side of both
+    limits, for 32- and 64-bit values, bit-packed and run-heavy id streams."""
+    r = rng(34)
+    cases = []
+    for data_type, dt, counts in ((L.INT, "<i4", (511, 512, 513, 5000, 16383, 16384, 16385)), (L.FLOAT, "<f4", (512, 16384)),
+                                  (L.LONG, "<i8", (255, 256, 257, 3000, 8191, 8192, 8193)), (L.DOUBLE, "<f8", (256, 8192))):
+        for m in counts:
+            vals = (np.arange(m) * 37 - 5000).astype(dt)
+            rows = vals[r.integers(0, m, 65536)]
+            rows[:m] = vals  # every entry is used
+            cases.append(oracle_case(rows, data_type, O.DICT_COMPRESS, name="type%d %d entries" % (data_type, m)))
+            runs = np.repeat(vals[r.integers(0, m, 3000)], r.integers(1, 40, 3000))[:60000]
+            runs = np.concatenate([vals, runs])[:65536]
+            cases.append(oracle_case(runs, data_type, O.DICT_COMPRESS, name="type%d %d entries, runs" % (data_type, m)))
+            cases.append(oracle_case(rows[:max(m, 1500)], data_type, O.SIMPLE_DICT, name="type%d %d entries, plain" % (data_type, m)))
+    three_ways(cases)
