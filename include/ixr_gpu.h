@@ -75,6 +75,14 @@ const char* ixr_last_error(void);
 /* Number of visible devices (0 when there is no GPU / HIP runtime). */
 int32_t ixr_device_count(void);
 
+/* Switches for A/B timing runs and for tests that must reach both variants of a kernel choice; no counterpart in the
+ * reference, not for production use.  They start from the environment (IXR_SPLIT_STR, IXR_LANE_WALK_FROM, read once per
+ * process) and apply to plans created afterwards:
+ *   "split_str"       1: string rows by the two-kernel form (per-row offsets through scratch), 0: the fused kernel
+ *   "lane_walk_from"  packs per launch from which one lane instead of one wave follows a framing stream; 0 = built-in choice
+ * Returns 0, or IXR_ERR_INVALID_ARGUMENT for an unknown name. */
+int32_t ixr_debug_switch(const char* name, int32_t value);
+
 /* ---- device memory helpers (so a JVM caller needs no HIP binding of its own) ---------------------------------- */
 void*   ixr_dev_alloc(int32_t device, uint64_t bytes);
 void    ixr_dev_free(int32_t device, void* dptr);

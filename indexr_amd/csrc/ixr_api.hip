@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -196,6 +197,7 @@ struct ixr_plan {
     bool profiling = false;
     bool overlap = true;  // numeric kernels on the auxiliary stream beside the string kernels (ixr_plan_set_overlap)
     int lane_walk_from = 0;  // see LaunchCtx::lane_walk_from
+    bool slice = false;    // see LaunchCtx::slice
     bool fused_str = true; // string rows: index and body copy in one kernel (IXR_SPLIT_STR=1: two kernels with per-row offsets in scratch, for A/B runs)
     std::vector<TimedLaunch> timed;       // launches of the last run (profiling only)
     std::vector<hipEvent_t> event_pool;   // reused across runs
@@ -219,6 +221,7 @@ struct ixr_plan {
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_dec[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
 };
 
+static void host_pipeline_release(ixr_plan* pl);
 extern "C" void ixr_plan_destroy(ixr_plan* plan) {
     if (!plan) return;
     (void)hipSetDevice(plan->device);
@@ -230,17 +233,34 @@ extern "C" void ixr_plan_destroy(ixr_plan* plan) {
     if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
     if (plan->ev_join) (void)hipEventDestroy(plan->ev_join);
     if (plan->aux) (void)hipStreamDestroy(plan->aux);
-    for (int b = 0; b < 2; b++) {
-        if (plan->h_din[b]) (void)hipFree(plan->h_din[b]);
-        if (plan->h_dout[b]) (void)hipFree(plan->h_dout[b]);
-        if (plan->ev_in[b]) (void)hipEventDestroy(plan->ev_in[b]);
-        if (plan->ev_dec[b]) (void)hipEventDestroy(plan->ev_dec[b]);
-        if (plan->ev_out[b]) (void)hipEventDestroy(plan->ev_out[b]);
-    }
-    if (plan->s_h2d) (void)hipStreamDestroy(plan->s_h2d);
-    if (plan->s_cmp) (void)hipStreamDestroy(plan->s_cmp);
-    if (plan->s_d2h) (void)hipStreamDestroy(plan->s_d2h);
+    host_pipeline_release(plan);
     delete plan;
+}
+
+// Switches for A/B runs and tests (not for production), read from the environment once per process.
+namespace {
+struct EnvSwitches {
+    std::atomic<int> split_str{0};       // IXR_SPLIT_STR=1: string rows by k_str_index + k_str_copy instead of k_str_bases + k_str_fused
+    std::atomic<int> slice{0};           // IXR_SLICE=1: sorted numeric dictionaries taken in order are decoded per tile (k_dict_slice)
+    std::atomic<int> lane_walk_from{0};  // IXR_LANE_WALK_FROM=n: packs per launch from which the lane walker replaces the window walker
+    EnvSwitches() {
+        if (const char* e = getenv("IXR_SPLIT_STR")) split_str = e[0] == '1';
+        if (const char* e = getenv("IXR_LANE_WALK_FROM")) lane_walk_from = atoi(e);
+        if (const char* e = getenv("IXR_SLICE")) slice = e[0] == '1';
+    }
+};
+EnvSwitches& env_switches() {
+    static EnvSwitches sw;
+    return sw;
+}
+}  // namespace
+extern "C" int32_t ixr_debug_switch(const char* name, int32_t value) {
+    if (!name) return fail(IXR_ERR_INVALID_ARGUMENT, "null switch name");
+    if (!strcmp(name, "split_str")) env_switches().split_str = value != 0;
+    else if (!strcmp(name, "lane_walk_from")) env_switches().lane_walk_from = value;
+    else if (!strcmp(name, "slice")) env_switches().slice = value != 0;
+    else return fail(IXR_ERR_INVALID_ARGUMENT, "unknown switch %s", name);
+    return 0;
 }
 
 static ixr_plan* plan_create(int32_t device, const ixr_pack_desc* descs, int32_t n_packs, uint64_t scratch_budget,
@@ -250,7 +270,8 @@ static ixr_plan* plan_create(int32_t device, const ixr_pack_desc* descs, int32_t
     if (scratch_budget == 0) scratch_budget = kDefaultScratchBudget;
     ixr_plan* pl = new ixr_plan();
     pl->device = device;
-    if (const char* e = getenv("IXR_SPLIT_STR")) pl->fused_str = !(e[0] == '1');
+    pl->fused_str = !env_switches().split_str;
+    pl->slice = env_switches().slice != 0;
     pl->n = n_packs;
     pl->descs.assign(descs, descs + n_packs);
     pl->hpacks.resize(n_packs);
@@ -309,7 +330,7 @@ static ixr_plan* plan_create(int32_t device, const ixr_pack_desc* descs, int32_t
         int n_str = 0;
         for (int i = 0; i < n_packs; i++) n_str += descs[i].data_type == IXR_STRING;
         if (2 * n_str >= n_packs) pl->lane_walk_from = 20000;
-        if (const char* e = getenv("IXR_LANE_WALK_FROM")) pl->lane_walk_from = atoi(e);  // A/B runs of the two framing walkers
+        if (env_switches().lane_walk_from) pl->lane_walk_from = env_switches().lane_walk_from;
     }
     // one allocation: [index area of all packs][bulk area of the largest group]; make the bulk offsets absolute
     index_total = align16(index_total) + 64;  // the bulk area never starts at offset 0 (k_str_copy may read 15 bytes before a dictionary)
@@ -445,6 +466,8 @@ static int32_t run_group_rows(ixr_plan* pl, Timer& T, Timer& TB, LaunchCtx& c, L
     run_group_front_num(pl, TN, cn, g);
     TN.run("k_dict_num<u32>", g.cnt[L_N32], [&] { launch_dict_num(cn, L + g.off[L_N32], g.cnt[L_N32], 32); });
     TN.run("k_dict_num<u64>", g.cnt[L_N64], [&] { launch_dict_num(cn, L + g.off[L_N64], g.cnt[L_N64], 64); });
+    TN.run("k_dict_slice<u32>", pl->slice ? g.cnt[L_N32] : 0, [&] { launch_dict_slice(cn, L + g.off[L_N32], g.cnt[L_N32], 32); });
+    TN.run("k_dict_slice<u64>", pl->slice ? g.cnt[L_N64] : 0, [&] { launch_dict_slice(cn, L + g.off[L_N64], g.cnt[L_N64], 64); });
     TN.run("k_copy_raw", g.cnt[L_RAW], [&] { launch_copy_raw(cn, L + g.off[L_RAW], g.cnt[L_RAW]); });
     run_group_front_str(pl, T, c, g, 0);
     if (pl->fused_str) {
@@ -471,6 +494,7 @@ extern "C" int32_t ixr_plan_run(ixr_plan* pl, const void* d_in, uint64_t in_byte
     Timer T{pl, st}, TB{pl, pl->aux};
     LaunchCtx c{st, pl->d_packs, pl->d_metas, (const uint8_t*)d_in, (uint8_t*)d_out, pl->d_scratch};
     c.lane_walk_from = pl->lane_walk_from;
+    c.slice = pl->slice;
     LaunchCtx cb = c;
     cb.stream = pl->aux;
     run_parse_all(pl, T, c);
@@ -488,22 +512,62 @@ extern "C" int32_t ixr_plan_run(ixr_plan* pl, const void* d_in, uint64_t in_byte
 // (What a reader without device-resident segments pays: IntegratedSegment.column(...).pack(...) loads a pack from
 // storage into host memory first, StorageColumn.java:78-116.)
 // ---------------------------------------------------------------------------------------------------------------
+static void host_pipeline_release(ixr_plan* pl) {
+    for (int b = 0; b < 2; b++) {
+        if (pl->h_din[b]) (void)hipFree(pl->h_din[b]);
+        if (pl->h_dout[b]) (void)hipFree(pl->h_dout[b]);
+        if (pl->ev_in[b]) (void)hipEventDestroy(pl->ev_in[b]);
+        if (pl->ev_dec[b]) (void)hipEventDestroy(pl->ev_dec[b]);
+        if (pl->ev_out[b]) (void)hipEventDestroy(pl->ev_out[b]);
+        pl->h_din[b] = pl->h_dout[b] = nullptr;
+        pl->ev_in[b] = pl->ev_dec[b] = pl->ev_out[b] = nullptr;
+    }
+    if (pl->s_h2d) (void)hipStreamDestroy(pl->s_h2d);
+    if (pl->s_cmp) (void)hipStreamDestroy(pl->s_cmp);
+    if (pl->s_d2h) (void)hipStreamDestroy(pl->s_d2h);
+    pl->s_h2d = pl->s_cmp = pl->s_d2h = nullptr;
+}
+
 static int32_t host_pipeline_setup(ixr_plan* pl) {
     if (!pl->spans.empty()) return 0;
     std::vector<ixr_plan::Span> spans;
     uint64_t max_in = 0, max_out = 0;
+    std::vector<std::pair<uint64_t, uint64_t>> outs, ins;  // (offset, bytes) of one group's packs
     for (const Group& g : pl->groups) {
         ixr_plan::Span sp{~0ull, 0, ~0ull, 0};
+        outs.clear();
+        ins.clear();
         for (int k = 0; k < g.cnt[L_ALL]; k++) {
             const ixr_pack_desc& d = pl->descs[(size_t)pl->group_list_entry(g, L_ALL, k)];
             sp.in_lo = std::min(sp.in_lo, d.in_off);
             sp.in_hi = std::max(sp.in_hi, d.in_off + (uint64_t)d.pack_size + IXR_IN_SLACK);
             sp.out_lo = std::min(sp.out_lo, d.out_off);
             sp.out_hi = std::max(sp.out_hi, align16(d.out_off + (uint64_t)d.data_size));
+            outs.push_back({d.out_off, (uint64_t)d.data_size});
+            ins.push_back({d.in_off, (uint64_t)d.pack_size});
         }
         // what one group copies out must not cover rows of another group: the packs lie in plan order in the output arena
         if (!spans.empty() && sp.out_lo < spans.back().out_hi)
             return fail(IXR_ERR_INVALID_ARGUMENT, "ixr_plan_run_host needs the packs laid out in plan order in the output arena");
+        // A group's rows travel back as ONE copy of its whole span, and the staging buffers are sized by span: the packs of a
+        // group must lie back to back (up to the alignment bytes) in the output arena, or the copy would overwrite whatever
+        // the caller keeps between them; in the input arena the same rule (plus the slack) bounds the staging memory.
+        std::sort(outs.begin(), outs.end());
+        for (size_t k = 0; k + 1 < outs.size(); k++) {
+            const uint64_t end = outs[k].first + outs[k].second;
+            if (outs[k + 1].first < end || outs[k + 1].first - end >= IXR_ARENA_ALIGN)
+                return fail(IXR_ERR_INVALID_ARGUMENT,
+                            "ixr_plan_run_host needs the packs of a group back to back in the output arena (at most %d alignment bytes "
+                            "between two packs' rows): offsets %llu and %llu", IXR_ARENA_ALIGN - 1, (unsigned long long)end,
+                            (unsigned long long)outs[k + 1].first);
+        }
+        std::sort(ins.begin(), ins.end());
+        for (size_t k = 0; k + 1 < ins.size(); k++) {
+            const uint64_t end = ins[k].first + ins[k].second;
+            if (ins[k + 1].first >= end && ins[k + 1].first - end > 4096)
+                return fail(IXR_ERR_INVALID_ARGUMENT, "ixr_plan_run_host needs the packs of a group close together in the input arena "
+                            "(gaps of at most 4096 bytes): offsets %llu and %llu", (unsigned long long)end, (unsigned long long)ins[k + 1].first);
+        }
         max_in = std::max(max_in, sp.in_hi - sp.in_lo);
         max_out = std::max(max_out, sp.out_hi - sp.out_lo);
         spans.push_back(sp);
@@ -519,7 +583,10 @@ static int32_t host_pipeline_setup(ixr_plan* pl) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&pl->s_h2d, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&pl->s_cmp, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&pl->s_d2h, hipStreamNonBlocking);
-    if (e != hipSuccess) return fail(IXR_ERR_OUT_OF_MEMORY, "staging buffers of the host pipeline: %s", hipGetErrorString(e));
+    if (e != hipSuccess) {
+        host_pipeline_release(pl);  // nothing half-made stays behind: the next call starts over
+        return fail(IXR_ERR_OUT_OF_MEMORY, "staging buffers of the host pipeline: %s", hipGetErrorString(e));
+    }
     pl->spans.swap(spans);
     return 0;
 }
@@ -539,34 +606,45 @@ extern "C" int32_t ixr_plan_run_host(ixr_plan* pl, const void* h_in, uint64_t in
     Timer T{pl, st}, TB{pl, pl->aux};
     const uint8_t* hin = (const uint8_t*)h_in;
     uint8_t* hout = (uint8_t*)h_out;
+    // A failure in the middle leaves copies in flight that read h_in or write h_out: every exit waits for the four streams
+    // first, so that the caller may free or reuse the arenas as soon as the call has returned.
+    auto drain = [&]() {
+        (void)hipStreamSynchronize(pl->s_d2h);
+        (void)hipStreamSynchronize(st);
+        (void)hipStreamSynchronize(pl->aux);
+        (void)hipStreamSynchronize(pl->s_h2d);
+    };
+#define HOST_TRY(expr) HIP_TRY(expr, { drain(); return IXR_ERR_HIP; })
     for (size_t gi = 0; gi < pl->groups.size(); gi++) {
         const Group& g = pl->groups[gi];
         const ixr_plan::Span& sp = pl->spans[gi];
         const int b = (int)(gi & 1);
         const uint64_t out_len = std::min(sp.out_hi, out_bytes) - sp.out_lo;
         // copy in: the staging buffer is free once the decode two groups back has read it
-        if (gi >= 2) HIP_TRY(hipStreamWaitEvent(pl->s_h2d, pl->ev_dec[b], 0), return IXR_ERR_HIP);
-        HIP_TRY(hipMemcpyAsync(pl->h_din[b], hin + sp.in_lo, sp.in_hi - sp.in_lo, hipMemcpyHostToDevice, pl->s_h2d), return IXR_ERR_HIP);
-        HIP_TRY(hipEventRecord(pl->ev_in[b], pl->s_h2d), return IXR_ERR_HIP);
+        if (gi >= 2) HOST_TRY(hipStreamWaitEvent(pl->s_h2d, pl->ev_dec[b], 0));
+        HOST_TRY(hipMemcpyAsync(pl->h_din[b], hin + sp.in_lo, sp.in_hi - sp.in_lo, hipMemcpyHostToDevice, pl->s_h2d));
+        HOST_TRY(hipEventRecord(pl->ev_in[b], pl->s_h2d));
         // decode: needs this group's input, and the output staging buffer copied out (two groups back)
-        HIP_TRY(hipStreamWaitEvent(st, pl->ev_in[b], 0), return IXR_ERR_HIP);
-        if (gi >= 2) HIP_TRY(hipStreamWaitEvent(st, pl->ev_out[b], 0), return IXR_ERR_HIP);
+        HOST_TRY(hipStreamWaitEvent(st, pl->ev_in[b], 0));
+        if (gi >= 2) HOST_TRY(hipStreamWaitEvent(st, pl->ev_out[b], 0));
         // the kernels address packs by arena offset: hand them the staging buffers shifted back by the group's first offset
         LaunchCtx c{st, pl->d_packs, pl->d_metas, (const uint8_t*)pl->h_din[b] - sp.in_lo, pl->h_dout[b] - sp.out_lo, pl->d_scratch};
+        c.slice = pl->slice;
         LaunchCtx cb = c;
         cb.stream = pl->aux;
         T.run("k_parse", g.cnt[L_ALL], [&] { launch_parse(c, pl->d_lists + g.off[L_ALL], g.cnt[L_ALL]); });
         rc = run_group_rows(pl, T, TB, c, cb, g);
-        if (rc) return rc;
-        HIP_TRY(hipEventRecord(pl->ev_dec[b], st), return IXR_ERR_HIP);
+        if (rc) { drain(); return rc; }
+        HOST_TRY(hipEventRecord(pl->ev_dec[b], st));
         // copy out
-        HIP_TRY(hipStreamWaitEvent(pl->s_d2h, pl->ev_dec[b], 0), return IXR_ERR_HIP);
-        HIP_TRY(hipMemcpyAsync(hout + sp.out_lo, pl->h_dout[b], out_len, hipMemcpyDeviceToHost, pl->s_d2h), return IXR_ERR_HIP);
-        HIP_TRY(hipEventRecord(pl->ev_out[b], pl->s_d2h), return IXR_ERR_HIP);
+        HOST_TRY(hipStreamWaitEvent(pl->s_d2h, pl->ev_dec[b], 0));
+        HOST_TRY(hipMemcpyAsync(hout + sp.out_lo, pl->h_dout[b], out_len, hipMemcpyDeviceToHost, pl->s_d2h));
+        HOST_TRY(hipEventRecord(pl->ev_out[b], pl->s_d2h));
     }
-    HIP_TRY(hipStreamSynchronize(pl->s_d2h), return IXR_ERR_HIP);
-    HIP_TRY(hipStreamSynchronize(st), return IXR_ERR_HIP);
-    HIP_TRY(hipStreamSynchronize(pl->s_h2d), return IXR_ERR_HIP);
+#undef HOST_TRY
+    HIP_TRY(hipStreamSynchronize(pl->s_d2h), { drain(); return IXR_ERR_HIP; });
+    HIP_TRY(hipStreamSynchronize(st), { drain(); return IXR_ERR_HIP; });
+    HIP_TRY(hipStreamSynchronize(pl->s_h2d), { drain(); return IXR_ERR_HIP; });
     HIP_TRY(hipGetLastError(), return IXR_ERR_HIP);
     return 0;
 }
@@ -618,23 +696,34 @@ static_assert(IXR_STATIC_MAX_PACKS == kStaticMaxPacks, "device code and the C AB
 // Decodes 1..IXR_STATIC_MAX_PACKS packs with every working array inside `block` (IXR_STATIC_SCRATCH_BYTES of device memory
 // laid out by static_layout).  Launches only: nothing is allocated, nothing is waited for.  `too_big`, when given, is set
 // instead of failing when the batch needs more working memory than the block holds.
+//   what = SMALL_ROWS          decoded rows at out_off (what ixr_plan_run does)
+//          SMALL_DICT_STRUCT   the uncompressed DictStruct of a DICT_COMPRESS pack at the start of d_out (one pack per call;
+//                              d_out holds 8 + data_size + 4 * obj_count bytes)
+//          SMALL_FROM_STRUCT   the "pack" is an uncompressed DictStruct, its rows go to out_off (one pack per call);
+//                              dict_cap = bytes reserved for the dictionary it carries
+enum SmallWhat { SMALL_ROWS = 0, SMALL_DICT_STRUCT = 1, SMALL_FROM_STRUCT = 2 };
 static int32_t decode_small(const ixr_pack_desc* descs, int32_t n_packs, const void* d_in, uint64_t in_bytes, void* d_out,
-                            uint64_t out_bytes, int32_t* d_status, hipStream_t st, uint8_t* block, bool* too_big) {
+                            uint64_t out_bytes, int32_t* d_status, hipStream_t st, uint8_t* block, bool* too_big,
+                            SmallWhat what = SMALL_ROWS, uint64_t dict_cap = 0) {
     StaticBatch batch;
     memset(&batch, 0, sizeof(batch));
     batch.n = n_packs;
+    batch.dict_cap = dict_cap;
+    if (what != SMALL_ROWS && n_packs != 1) return fail(IXR_ERR_BUG, "the DictStruct forms take one pack per call");
     for (int i = 0; i < n_packs; i++) {
         const ixr_pack_desc& d = descs[i];
         if (d.pack_size < 0 || d.data_size < 0 || d.obj_count <= 0 || d.obj_count > IXR_PACK_MAX_ROWS ||
             (d.in_off % IXR_ARENA_ALIGN) || (d.out_off % IXR_ARENA_ALIGN) || d.data_type < IXR_INT || d.data_type > IXR_STRING)
             return fail(IXR_ERR_INVALID_ARGUMENT, "pack %d: bad descriptor (sizes, obj_count 1..65536, 16-byte aligned offsets, data type)", i);
-        if (d.in_off + (uint64_t)d.pack_size + IXR_IN_SLACK > in_bytes)
+        // written so that offsets near 2^64 cannot wrap past the check
+        const uint64_t in_need = (uint64_t)d.pack_size + IXR_IN_SLACK, out_need = (uint64_t)d.data_size;
+        if (d.in_off > in_bytes || in_need > in_bytes - d.in_off)
             return fail(IXR_ERR_INVALID_ARGUMENT, "pack %d: the input arena must hold the pack and %d bytes of slack", i, IXR_IN_SLACK);
-        if (d.out_off + (uint64_t)d.data_size > out_bytes) return fail(IXR_ERR_INVALID_ARGUMENT, "pack %d: output outside the arena", i);
+        if (d.out_off > out_bytes || out_need > out_bytes - d.out_off) return fail(IXR_ERR_INVALID_ARGUMENT, "pack %d: output outside the arena", i);
         memcpy(&batch.d[i], &d, sizeof(SmallDesc));
     }
     int counts[SL_COUNT];
-    const uint64_t need = static_layout(batch.d, n_packs, nullptr, nullptr, counts);
+    const uint64_t need = static_layout(batch.d, n_packs, dict_cap, nullptr, nullptr, counts);
     if (need > IXR_STATIC_SCRATCH_BYTES) {
         if (too_big) { *too_big = true; return 0; }
         return fail(IXR_ERR_INVALID_ARGUMENT, "the batch needs %llu bytes of working memory, the static scratch holds %llu: pass fewer packs per call",
@@ -645,20 +734,44 @@ static int32_t decode_small(const ixr_pack_desc* descs, int32_t n_packs, const v
     const int* lists = (const int*)(block + kStaticListOff);
     const int *all = lists + SL_ALL * kStaticMaxPacks, *n32 = lists + SL_N32 * kStaticMaxPacks, *n64 = lists + SL_N64 * kStaticMaxPacks,
               *str = lists + SL_STR * kStaticMaxPacks, *raw = lists + SL_RAW * kStaticMaxPacks;
-    launch_parse(c, all, counts[SL_ALL]);
-    launch_delta(c, n32, counts[SL_N32], 32, 1);
-    launch_delta(c, n64, counts[SL_N64], 64, 1);
-    launch_dict_num(c, n32, counts[SL_N32], 32);
-    launch_dict_num(c, n64, counts[SL_N64], 64);
-    launch_copy_raw(c, raw, counts[SL_RAW]);
-    launch_delta(c, str, counts[SL_STR], 32, 2);
-    launch_str_dict_scan(c, str, counts[SL_STR]);
-    launch_front_summary(c, str, counts[SL_STR], 0);
-    launch_front_combine(c, str, counts[SL_STR], 0);
-    launch_front_decode(c, str, counts[SL_STR], 0);
-    launch_front_serial(c, str, counts[SL_STR]);
-    launch_str_bases(c, str, counts[SL_STR]);
-    launch_str_fused(c, str, counts[SL_STR]);
+    if (what == SMALL_FROM_STRUCT) {
+        // PackCompressor_VLT.getDataFromDictStruct (:188-213): plain entries and 4-byte ids straight out of the DictStruct
+        launch_ds_meta(c, all, 1);
+        if (counts[SL_STR]) {
+            launch_str_dict_scan(c, all, 1);
+            launch_ds_rows(c, all, 1, 2);
+            launch_row_scan(c, all, 1);
+            launch_str_copy(c, all, 1);
+        } else {
+            launch_delta(c, all, 1, counts[SL_N32] ? 32 : 64, 1);
+            launch_ds_rows(c, all, 1, counts[SL_N32] ? 0 : 1);
+        }
+    } else {
+        const int use_ds = what == SMALL_DICT_STRUCT;
+        c.dict_only = use_ds;
+        launch_parse(c, all, counts[SL_ALL]);
+        launch_delta(c, n32, counts[SL_N32], 32, 1);
+        launch_delta(c, n64, counts[SL_N64], 64, 1);
+        if (!use_ds) {
+            launch_dict_num(c, n32, counts[SL_N32], 32);
+            launch_dict_num(c, n64, counts[SL_N64], 64);
+            launch_dict_slice(c, n32, counts[SL_N32], 32);
+            launch_dict_slice(c, n64, counts[SL_N64], 64);
+            launch_copy_raw(c, raw, counts[SL_RAW]);
+        }
+        launch_delta(c, str, counts[SL_STR], 32, 2);
+        launch_str_dict_scan(c, str, counts[SL_STR]);
+        launch_front_summary(c, str, counts[SL_STR], use_ds);
+        launch_front_combine(c, str, counts[SL_STR], use_ds);
+        launch_front_decode(c, str, counts[SL_STR], use_ds);
+        launch_front_serial(c, str, counts[SL_STR]);
+        if (use_ds) {
+            launch_dict_struct(c, all, 1);  // PackCompressor_VLT.getDictStruct (:172-186)
+        } else {
+            launch_str_bases(c, str, counts[SL_STR]);
+            launch_str_fused(c, str, counts[SL_STR]);
+        }
+    }
     launch_export_status(st, c.metas, n_packs, d_status);
     HIP_TRY(hipGetLastError(), return IXR_ERR_HIP);
     return 0;
@@ -691,7 +804,8 @@ static void attribute_bytes(ixr_plan* pl, const std::vector<PackMeta>& metas, st
             case K_DELTA_NUM: by[w32 ? "k_delta<u32>" : "k_delta<u64>"] += ps + ds; break;
             case K_DICT_NUM:
                 by[w32 ? "k_delta<u32>" : "k_delta<u64>"] += m.ids_off;                     // header + entries
-                by[w32 ? "k_dict_num<u32>" : "k_dict_num<u64>"] += (ps - m.ids_off) + ds;   // id stream in, rows out
+                if (m.sliced) by[w32 ? "k_dict_slice<u32>" : "k_dict_slice<u64>"] += (ps - m.ids_off) + ds;
+                else by[w32 ? "k_dict_num<u32>" : "k_dict_num<u64>"] += (ps - m.ids_off) + ds;   // id stream in, rows out
                 break;
             case K_DICT_STR: {
                 const uint64_t index = 4 * (n + 1), body = ds > index ? ds - index : 0;
@@ -841,7 +955,23 @@ struct PackCtx {
         }
         return true;
     }
+    // called with the context's device current
+    void release() {
+        if (stream) (void)hipStreamDestroy(stream);
+        if (d_in) (void)hipFree(d_in);
+        if (d_out) (void)hipFree(d_out);
+        if (d_block) (void)hipFree(d_block);
+        if (d_status) (void)hipFree(d_status);
+        if (h_in) (void)hipHostFree(h_in);
+        if (h_out) (void)hipHostFree(h_out);
+        if (h_status) (void)hipHostFree(h_status);
+    }
 };
+// A device keeps at most kPoolIdleMax idle contexts (calls that overlap beyond that build and drop their own), and a context
+// whose buffers grew beyond kPoolKeepBytes (a pack of very long strings) is dropped after its call instead of kept: what stays
+// allocated per device is bounded by kPoolIdleMax * (32 MiB working block + 2 * kPoolKeepBytes device + 2 * kPoolKeepBytes pinned).
+constexpr size_t kPoolIdleMax = 8;
+constexpr uint64_t kPoolKeepBytes = 16ull << 20;
 struct PackCtxPool {
     std::mutex mu;
     std::vector<PackCtx*> idle[64];
@@ -863,20 +993,32 @@ struct PackCtxLease {
     }
     ~PackCtxLease() {
         PackCtxPool& pool = pack_ctx_pool();
-        std::lock_guard<std::mutex> g(pool.mu);
-        pool.idle[device].push_back(ctx);
+        if (ctx->in_cap <= kPoolKeepBytes && ctx->out_cap <= kPoolKeepBytes) {
+            std::lock_guard<std::mutex> g(pool.mu);
+            if (pool.idle[device].size() < kPoolIdleMax) { pool.idle[device].push_back(ctx); return; }
+        }
+        if (hipSetDevice(device) == hipSuccess) ctx->release();
+        delete ctx;
     }
 };
 }  // namespace
 
-// Rows of one pack through a pooled context: one copy in, the small-batch kernels, status and rows out, one wait.
-// Returns 1 when the pack needs more working memory than a context holds (the caller then takes the plan path).
-static int32_t single_pack_pooled(int32_t device, const ixr_pack_desc& d, const void* in, void* out, int32_t* rc_out) {
+// One pack through a pooled context: one copy in, the small-batch kernels, status and result out, one wait.  `d` describes
+// the pack as the kernels see it, `in_size` bytes of `in` go in, `copy_out` bytes come back from the start of the device
+// output, `dev_out_bytes` is the size the device output needs.  Returns 1 when the pack needs more working memory than a
+// context holds (the caller then takes the plan path), else 0 with the call's result in *rc_out.
+static int32_t single_pack_pooled(int32_t device, const ixr_pack_desc& d, const void* in, void* out, uint64_t copy_out,
+                                  uint64_t dev_out_bytes, SmallWhat what, uint64_t dict_cap, int32_t* rc_out) {
     if (device < 0 || device >= 64) return 1;
     int32_t rc = ixr_init(device);
     if (rc) { *rc_out = rc; return 0; }
+    {   // nothing is reserved for a pack the working block cannot take
+        SmallDesc sd;
+        memcpy(&sd, &d, sizeof(sd));
+        if (static_layout(&sd, 1, dict_cap, nullptr, nullptr, nullptr) > IXR_STATIC_SCRATCH_BYTES) return 1;
+    }
     const uint64_t in_bytes = align16((uint64_t)d.pack_size) + IXR_IN_SLACK;
-    const uint64_t out_bytes = align16((uint64_t)std::max(d.data_size, 16)) + 16;
+    const uint64_t out_bytes = std::max(align16(std::max<uint64_t>(copy_out, 16)) + 16, dev_out_bytes);
     PackCtxLease lease(device);
     PackCtx& x = *lease.ctx;
     if (hipSetDevice(device) != hipSuccess || !x.reserve(in_bytes, out_bytes)) {
@@ -888,7 +1030,7 @@ static int32_t single_pack_pooled(int32_t device, const ixr_pack_desc& d, const 
     bool too_big = false;
     hipError_t e = hipMemcpyAsync(x.d_in, x.h_in, in_bytes, hipMemcpyHostToDevice, x.stream);
     if (e == hipSuccess) {
-        rc = decode_small(&d, 1, x.d_in, in_bytes, x.d_out, out_bytes, x.d_status, x.stream, x.d_block, &too_big);
+        rc = decode_small(&d, 1, x.d_in, in_bytes, x.d_out, out_bytes, x.d_status, x.stream, x.d_block, &too_big, what, dict_cap);
         if (rc || too_big) {
             (void)hipStreamSynchronize(x.stream);
             if (too_big) return 1;
@@ -897,11 +1039,14 @@ static int32_t single_pack_pooled(int32_t device, const ixr_pack_desc& d, const 
         }
         e = hipMemcpyAsync(x.h_status, x.d_status, 4, hipMemcpyDeviceToHost, x.stream);
     }
-    if (e == hipSuccess && d.data_size > 0) e = hipMemcpyAsync(x.h_out, x.d_out, (size_t)d.data_size, hipMemcpyDeviceToHost, x.stream);
+    if (e == hipSuccess && copy_out > 0) e = hipMemcpyAsync(x.h_out, x.d_out, (size_t)copy_out, hipMemcpyDeviceToHost, x.stream);
     if (e == hipSuccess) {
-        // a decode is tens of microseconds: poll for it before falling back to a blocking wait, whose wake-up alone can
-        // take several times as long
-        for (int spin = 0; spin < 20000 && (e = hipStreamQuery(x.stream)) == hipErrorNotReady; spin++) {}
+        // A decode is tens to hundreds of microseconds: the calling thread polls the stream for up to kPollNs before it
+        // falls back to a blocking wait, whose wake-up alone can take several times a short decode.
+        constexpr int64_t kPollNs = 1000000;
+        const auto t0 = std::chrono::steady_clock::now();
+        while ((e = hipStreamQuery(x.stream)) == hipErrorNotReady &&
+               std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() < kPollNs) {}
         if (e == hipErrorNotReady) e = hipStreamSynchronize(x.stream);
     }
     if (e != hipSuccess) {
@@ -914,7 +1059,7 @@ static int32_t single_pack_pooled(int32_t device, const ixr_pack_desc& d, const 
         *rc_out = fail(status, "decode failed with code %d", status);
         return 0;
     }
-    memcpy(out, x.h_out, (size_t)d.data_size);
+    memcpy(out, x.h_out, (size_t)copy_out);
     *rc_out = status;
     return 0;
 }
@@ -952,9 +1097,12 @@ static int32_t single_pack(int32_t device, int32_t data_type, int32_t encode_typ
         }
         dict_cap_override = (uint64_t)in_size;
     }
-    if (mode == 0 && obj_count <= IXR_PACK_MAX_ROWS) {
+    if (obj_count <= IXR_PACK_MAX_ROWS) {
+        // the pooled path: no allocation, no plan (all three calls DataPack.decompress makes, DataPack.java:166-186)
         int32_t rc_fast = 0;
-        if (single_pack_pooled(device, d, in, out, &rc_fast) == 0) return rc_fast;
+        const uint64_t copy_out = mode == 1 ? (uint64_t)ds_size : (uint64_t)d.data_size;
+        const uint64_t dev_out = mode == 1 ? align16(dict_struct_bound(d)) + 16 : 0;
+        if (single_pack_pooled(device, d, in, out, copy_out, dev_out, (SmallWhat)mode, dict_cap_override, &rc_fast) == 0) return rc_fast;
     }
     ixr_plan* pl = plan_create(device, &d, 1, 0, dict_cap_override);
     if (!pl) return g_code < 0 ? g_code : IXR_ERR_HIP;  // plan_create recorded why (no device, bad descriptor, memory)

@@ -602,6 +602,7 @@ __device__ __forceinline__ void pack_header(const DevPack& P, const uint8_t* bas
     const int W = P.width;  // 32, 64 or 0 (strings)
     m.status = 0; m.kind = K_NONE; m.entry_count = 0; m.id_bw = 0; m.ids_off = 0; m.ids_len = 0; m.entries_off = 0;
     m.entries_plain = 0; m.sfx_off = 0; m.sfx_len = 0; m.dict_struct_size = 0; m.max_len = 0; m.front_blocks = 0; m.front_stride = 0;
+    m.sliced = 0;
     m.s[0].n = m.s[1].n = 0; m.s[0].in_off = m.s[1].in_off = 0; m.s[0].first = m.s[1].first = 0;
     err = 0;
     consumed = 0;
@@ -1008,9 +1009,16 @@ template <typename U> __device__ __forceinline__ U wave_incl_scan(U v) {
 // scan and an LDS combine of the waves' totals give the running values; the carry travels in a register.  Replaces the two passes of DeltaCodec.decodeIntsBlock / decodeLongsBlock (DeltaCodec.java:112-127, 216-231).
 // Also copies plain (uncompressed) dictionary entries into the aligned scratch dictionary (PlainCodec.java:48-70).
 // ---------------------------------------------------------------------------------------------------------------
+// How the numeric dictionary packs are shared out between the row kernels, by the size and use of their dictionaries:
+// 2 to 64 KB: looked up in LDS (k_dict_lds); larger ones whose rows ask for the entries in order: k_dict_slice; the rest
+// (and dictionaries below 2 KB, which stay in the vector L1): gathers from the scratch dictionary (k_dict_num).
+constexpr uint32_t kDictLdsBytes = 65536, kDictLdsMinBytes = 2048;
+constexpr uint32_t kSliceBlocks = 9;      // 128-entry blocks k_dict_slice decodes per round: a stretch of 1025 entries at any alignment
+constexpr uint32_t kSliceSpan = 1024;     // largest rise of the ids over a tile that one round covers
+
 template <typename U, int kThreads>
 __global__ __launch_bounds__(kThreads) void k_delta(const DevPack* __restrict__ packs, const int* __restrict__ list,
-                                               const PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
+                                               PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                uint8_t* __restrict__ out, uint8_t* __restrict__ scratch, int dict_only) {
     const int pi = list[pack_slot_remap(blockIdx.x, gridDim.x)];
     const int sk = blockIdx.y;
@@ -1036,6 +1044,35 @@ __global__ __launch_bounds__(kThreads) void k_delta(const DevPack* __restrict__ 
     }
     const StreamDesc s = sk == 0 ? M.s[0] : M.s[1];
     if (s.n == 0) return;
+
+    // A sorted dictionary whose rows ask for its entries in order (a column that grows with the row number: timestamps,
+    // counters; the ids then step by 0 or 1) is not written to scratch at all: a tile of rows needs a stretch of at most
+    // kSliceSpan entries, which k_dict_slice decodes into LDS by itself from the value in front of the stretch's first
+    // 128-entry block.  Those values, one per block, are all this kernel leaves for such a pack.  The choice is made from the
+    // id of every tile's first row (the segment records of the framing walk give it without walking the stream): they must
+    // rise from tile to tile by at most kSliceSpan.  Ids that misbehave inside a tile cost k_dict_slice extra rounds, no more.
+    bool sliced = false;
+    if (kind == K_DICT_NUM && dict_only == 2 && (uint64_t)M.entry_count * sizeof(U) > kDictLdsBytes) {
+        __shared__ int s_sliced;
+        if (tid < 64) {
+            const uint32_t ntiles = ((uint32_t)P.obj_count + kRleTile - 1) / kRleTile, ec = M.entry_count, bw = M.id_bw;
+            uint32_t id = ec - 1u;
+            if ((uint32_t)tid < ntiles) {
+                const uint4 rec = ((const uint4*)(scratch + P.s_restart))[tid];
+                id = (rec.w & 1u) ? extract32(base + rec.x, ((uint32_t)tid * kRleTile - rec.y) * bw, bw) : (rec.w >> 1);
+            }
+            uint32_t next = (uint32_t)__shfl_down((int)id, 1);
+            if ((uint32_t)tid + 1 >= ntiles) next = ec - 1u;
+            const bool ok = (uint32_t)tid >= ntiles || (id < ec && next >= id && next - id <= kSliceSpan);
+            const uint64_t no = __builtin_amdgcn_ballot_w64(!ok);
+            if (tid == 0) {
+                s_sliced = no == 0;
+                if (no == 0) metas[pi].sliced = 1;
+            }
+        }
+        __syncthreads();
+        sliced = s_sliced != 0;
+    }
 
     U* dst;
     if (kind == K_DELTA_NUM) dst = (U*)(out + P.out_off);
@@ -1148,7 +1185,10 @@ __global__ __launch_bounds__(kThreads) void k_delta(const DevPack* __restrict__ 
             wtotal += t;
         }
         const U pre = carry + wprefix + (incl - d[V - 1]);
-        if (i0 + V - 1 < n) {
+        if (sliced) {
+            // the value in front of every 128-entry block (`pre` is the entry before this thread's first one)
+            if ((i0 & (kBlock - 1)) == 0 && i0 < n) dst[i0 >> 7] = pre;
+        } else if (i0 + V - 1 < n) {
             if constexpr (sizeof(U) == 4) {
 #pragma unroll
                 for (int q = 0; q < V; q += 4) *(uint4*)(dst + i0 + q) = make_uint4(d[q] + pre, d[q + 1] + pre, d[q + 2] + pre, d[q + 3] + pre);
@@ -1290,7 +1330,6 @@ __device__ __forceinline__ bool tile_ctx(TileCtx& t, const DevPack* packs, const
 // Dictionaries of 2 to 64 KB are looked up in LDS (k_dict_lds).  Smaller ones stay in the vector L1 anyway and their packs
 // -- few distinct values, often run-heavy id streams whose expansion is the work -- are better off with the smaller
 // workgroups of k_dict_num (measured: 16 values in runs lose a third in the LDS kernel); larger ones do not fit.
-constexpr uint32_t kDictLdsBytes = 65536, kDictLdsMinBytes = 2048;
 template <typename U> __device__ __forceinline__ bool dict_in_lds(uint32_t entry_count) {
     const uint32_t bytes = entry_count * (uint32_t)sizeof(U);
     return bytes >= kDictLdsMinBytes && bytes <= kDictLdsBytes;
@@ -1310,6 +1349,7 @@ __global__ __launch_bounds__(256) void k_dict_num(const DevPack* __restrict__ pa
     if (dict_in_lds<U>(t.ec)) return;  // k_dict_lds takes this pack
     const DevPack& P = packs[t.pi];
     const PackMeta& M = metas[t.pi];
+    if (M.sliced) return;              // k_dict_slice takes this pack
     const U* __restrict__ dict = (const U*)(scratch + P.s_dict);
     U* __restrict__ dst = (U*)(out + P.out_off) + t.tile_start;
     uint16_t* ids = s_ids[threadIdx.x >> 6];
@@ -1355,7 +1395,8 @@ __global__ __launch_bounds__(256) void k_dict_num(const DevPack* __restrict__ pa
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_dict_lds: numeric dictionary packs whose dictionary fits 48 KB.  A kernel that gathers from memory and stores runs at the
+// k_dict_lds: numeric dictionary packs whose dictionary is 2 to 64 KB (kDictLdsMinBytes .. kDictLdsBytes; about 129 KB of static
+// LDS per workgroup with the 16 id tiles and stream windows).  A kernel that gathers from memory and stores runs at the
 // speed of a copy, however well the gathers hit the caches: loads and stores share the vector memory path.  Lookups out of
 // LDS leave that path to the id windows and the stores.  One workgroup of 16 waves per pack: the dictionary is copied
 // to LDS once (coalesced), then every wave takes every 16th tile: expands its ids and looks its rows up there.
@@ -1418,6 +1459,135 @@ __global__ __launch_bounds__(1024) void k_dict_lds(const DevPack* __restrict__ p
         }
     }
     if (bad) metas[pi].status = E_CORRUPT;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_dict_slice: numeric dictionary packs marked `sliced` by k_delta (sorted dictionary, rows that ask for its entries in
+// order).  One wave per tile of kRleTile rows: expands the tile's ids, takes their range [lo, hi], decodes the 128-entry
+// blocks of the DELTA-coded entry stream that cover it into LDS -- every block starts from the value k_delta left for it,
+// so the blocks are independent of each other: bit extraction, + minDelta, one wave scan per block
+// (DeltaCodec.decodeLongsBlock, DeltaCodec.java:216-231) -- and looks the rows up there
+// (DictStruct.decodeLongs, DictStruct.java:66-80).  The dictionary itself never exists in memory.  A tile whose ids span
+// more than kSliceBlocks blocks takes further rounds over the following blocks; every row is produced in the round that
+// holds its entry, so any id stream decodes correctly, only not quickly.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename U>
+__global__ __launch_bounds__(256) void k_dict_slice(const DevPack* __restrict__ packs, const int* __restrict__ list,
+                                                    PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
+                                                    uint8_t* __restrict__ out, const uint8_t* __restrict__ scratch) {
+    // per wave: the stream window and the id tile while the ids are expanded, then the decoded stretch of the dictionary
+    constexpr uint32_t kSliceBytes = kSliceBlocks * kBlock * (uint32_t)sizeof(U);
+    constexpr uint32_t kWaveLds = (SmallWin::kAlloc + 2 * kRleTile > kSliceBytes ? SmallWin::kAlloc + 2 * kRleTile : kSliceBytes) + 16;
+    __shared__ __align__(16) uint8_t smem[4][kWaveLds];
+    TileCtx t;
+    if (!tile_ctx(t, packs, list, metas, K_DICT_NUM, 0)) return;
+    const PackMeta& M = metas[t.pi];
+    if (!M.sliced) return;
+    const DevPack& P = packs[t.pi];
+    const uint8_t* base = in + P.in_off;
+    const uint32_t lane = threadIdx.x & 63, cnt = t.tile_end - t.tile_start, ec = t.ec;
+    uint8_t* wl = smem[threadIdx.x >> 6];
+    U* __restrict__ dst = (U*)(out + P.out_off) + t.tile_start;
+    // ---- the tile's ids: 16 per lane, two neighbouring rows of every 128 (as k_dict_num)
+    uint32_t id[16];
+    bool bad = false;
+    {
+        uint16_t* ids = (uint16_t*)(wl + SmallWin::kAlloc);
+        SmallWin w;
+        w.init(base, (uint32_t)P.pack_size, wl);
+        rle_tile_expand(w, M.id_bw, M.ids_off + 4 + M.ids_len, uniform_load((const uint4*)(scratch + P.s_restart) + t.tile), t.tile_start,
+                        t.tile_end, ids);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t r = q * 128 + 2 * lane;
+            const uint32_t two = ((const uint32_t*)ids)[q * 64 + lane];
+            id[2 * q] = r < cnt ? (two & 0xFFFFu) : 0xFFFFFFFFu;      // rows past the tile's end take part in nothing
+            id[2 * q + 1] = r + 1 < cnt ? (two >> 16) : 0xFFFFFFFFu;
+            if (r < cnt && id[2 * q] >= ec) { bad = true; id[2 * q] = 0xFFFFFFFFu; }
+            if (r + 1 < cnt && id[2 * q + 1] >= ec) { bad = true; id[2 * q + 1] = 0xFFFFFFFFu; }
+        }
+        SmallWin::wave_lds_sync();  // window and id tile are dead: their memory becomes the dictionary stretch
+    }
+    uint32_t lo = 0xFFFFFFFFu, hi = 0;
+#pragma unroll
+    for (int q = 0; q < 16; q++)
+        if (id[q] != 0xFFFFFFFFu) { lo = min(lo, id[q]); hi = max(hi, id[q]); }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, d));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, d));
+    }
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    // ---- the entry stream's index (left by the framing walk) and the block values (left by k_delta)
+    const int64_t* min_delta = (const int64_t*)(scratch + P.s_idx[0]);
+    const uint32_t* mb = (const uint32_t*)(min_delta + (P.obj_count + kBlock - 1) / kBlock);
+    const U* bases = (const U*)(scratch + P.s_dict);
+    U* slice = (U*)wl;
+    U v[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) v[q] = 0;
+    if (lo <= hi) {
+        const uint32_t nblk = (ec + kBlock - 1) / kBlock;
+        for (uint32_t b0 = lo >> 7; b0 <= (hi >> 7); b0 += kSliceBlocks) {
+            const uint32_t nb = min(kSliceBlocks, min(nblk, (hi >> 7) + 1u) - b0);  // wave-uniform
+            // a lane takes two neighbouring entries of every block (one mini-block header serves both); all loads first
+            uint32_t hdr[kSliceBlocks];
+            U md[kSliceBlocks], pv[kSliceBlocks];
+            const uint32_t e0 = 2 * lane;
+#pragma unroll
+            for (uint32_t k = 0; k < kSliceBlocks; k++) {
+                const uint32_t b = min(b0 + k, nblk - 1);
+                hdr[k] = mb[b * 4 + (lane >> 4)];
+                md[k] = (U)min_delta[b];
+                pv[k] = bases[b];
+            }
+            U a0[kSliceBlocks], a1[kSliceBlocks];
+#pragma unroll
+            for (uint32_t k = 0; k < kSliceBlocks; k++) {
+                const uint32_t b = min(b0 + k, nblk - 1);
+                const uint32_t bw = hdr[k] >> 24, in_blk = min((uint32_t)kBlock, ec - b * kBlock);
+                const uint8_t* src = base + (hdr[k] & 0xFFFFFFu);
+                // entries past the stream's end contribute nothing (their bits may lie past the pack)
+                a0[k] = e0 < in_blk ? extract<U>(src, (e0 & 31u) * bw, bw) + md[k] : (U)0;
+                a1[k] = e0 + 1 < in_blk ? extract<U>(src, ((e0 + 1) & 31u) * bw, bw) + md[k] : (U)0;
+            }
+            SmallWin::wave_lds_sync();  // the round before has been read
+#pragma unroll
+            for (uint32_t k = 0; k < kSliceBlocks; k++) {
+                if (k < nb) {
+                    const U two = a0[k] + a1[k];
+                    const U before = pv[k] + wave_incl_scan<U>(two) - two;
+                    if constexpr (sizeof(U) == 8) {
+                        *(ulonglong2*)(slice + k * kBlock + e0) = make_ulonglong2(before + a0[k], before + two);
+                    } else {
+                        *(uint2*)(slice + k * kBlock + e0) = make_uint2(before + a0[k], before + two);
+                    }
+                }
+            }
+            SmallWin::wave_lds_sync();
+            const uint32_t s0 = b0 * kBlock, s1 = s0 + nb * kBlock;
+#pragma unroll
+            for (int q = 0; q < 16; q++)
+                if (id[q] >= s0 && id[q] < s1) v[q] = slice[id[q] - s0];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const uint32_t r = q * 128 + 2 * lane;
+        if (r + 1 < cnt) {
+            if constexpr (sizeof(U) == 4) {
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                u32x2 tv = {(uint32_t)v[2 * q], (uint32_t)v[2 * q + 1]};
+                __builtin_nontemporal_store(tv, (u32x2*)(dst + r));
+            } else {
+                typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+                u64x2 tv = {(uint64_t)v[2 * q], (uint64_t)v[2 * q + 1]};
+                __builtin_nontemporal_store(tv, (u64x2*)(dst + r));
+            }
+        } else if (r < cnt) dst[r] = v[2 * q];
+    }
+    if (bad) metas[t.pi].status = E_CORRUPT;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1540,7 +1710,14 @@ __global__ __launch_bounds__(256) void k_str_dict_scan(const DevPack* __restrict
         bad = block_or(bad);
         mx = block_max(mx);
         if (bad) { if (tid == 0) M.status = E_CORRUPT; return; }
-        for (uint64_t i = tid; i < bytes; i += 256) dict[i] = src[i];
+        // 16 bytes at a time (the scratch dictionary is 16-byte aligned, the entries in the pack are wherever they are), the
+        // last bytes one by one
+        for (uint64_t i = tid; i < bytes / 16; i += 256) {
+            uint4 v;
+            __builtin_memcpy(&v, src + 16 * i, 16);
+            *(uint4*)(dict + 16 * i) = v;
+        }
+        for (uint64_t i = (bytes & ~15ull) + tid; i < bytes; i += 256) dict[i] = src[i];
         if (tid == 0) M.max_len = mx;
         return;
     }
@@ -2627,7 +2804,7 @@ __global__ void k_ds_meta(const DevPack* __restrict__ packs, const int* __restri
     PackMeta m;
     m.status = P.pack_size; m.kind = P.width ? K_DICT_NUM : K_DICT_STR; m.entry_count = 0; m.id_bw = 0; m.ids_off = 0;
     m.ids_len = 0; m.entries_off = 4; m.entries_plain = 1; m.sfx_off = 0; m.sfx_len = 0; m.dict_struct_size = psz; m.max_len = 0;
-    m.front_blocks = 0; m.front_stride = 0;
+    m.front_blocks = 0; m.front_stride = 0; m.sliced = 0;
     m.s[0].n = m.s[1].n = 0; m.s[0].in_off = m.s[1].in_off = 0; m.s[0].first = m.s[1].first = 0;
     int32_t err = 0;
     if (psz < 8 || n == 0 || n > 65536u) err = E_CORRUPT;
@@ -3287,7 +3464,7 @@ __global__ void k_static_setup(StaticBatch batch, uint8_t* block) {
     for (uint32_t i = threadIdx.x; i < (uint32_t)(sizeof(PackMeta) * kStaticMaxPacks / 4); i += blockDim.x) ((uint32_t*)metas)[i] = 0;
     if (threadIdx.x == 0) {
         int counts[SL_COUNT];
-        static_layout(batch.d, batch.n, packs, lists, counts);
+        static_layout(batch.d, batch.n, batch.dict_cap, packs, lists, counts);
     }
 }
 __global__ void k_export_status(const PackMeta* __restrict__ metas, int count, int32_t* __restrict__ d_status) {
@@ -3316,13 +3493,16 @@ void launch_parse(const LaunchCtx& c, const int* list, int count) {
 }
 void launch_delta(const LaunchCtx& c, const int* list, int count, int width, int streams) {
     if (count <= 0) return;
+    // the kernel's mode word: 0 rows and dictionaries, 1 dictionaries only, 2 as 0 with sorted dictionaries that are taken in
+    // order left to k_dict_slice
+    const int mode = c.dict_only ? 1 : (c.slice ? 2 : 0);
     const bool few = (long)count * streams < 512;  // fewer streams than two per compute unit: long workgroups, short chains
     if (width == 64) {
-        if (few) hipLaunchKernelGGL((k_delta<uint64_t, 1024>), dim3(count, streams), dim3(1024), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch, c.dict_only);
-        else hipLaunchKernelGGL((k_delta<uint64_t, 256>), dim3(count, streams), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch, c.dict_only);
+        if (few) hipLaunchKernelGGL((k_delta<uint64_t, 1024>), dim3(count, streams), dim3(1024), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch, mode);
+        else hipLaunchKernelGGL((k_delta<uint64_t, 256>), dim3(count, streams), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch, mode);
     } else {
-        if (few) hipLaunchKernelGGL((k_delta<uint32_t, 1024>), dim3(count, streams), dim3(1024), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch, c.dict_only);
-        else hipLaunchKernelGGL((k_delta<uint32_t, 256>), dim3(count, streams), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch, c.dict_only);
+        if (few) hipLaunchKernelGGL((k_delta<uint32_t, 1024>), dim3(count, streams), dim3(1024), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch, mode);
+        else hipLaunchKernelGGL((k_delta<uint32_t, 256>), dim3(count, streams), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch, mode);
     }
 }
 void launch_dict_num(const LaunchCtx& c, const int* list, int count, int width) {
@@ -3338,6 +3518,12 @@ void launch_dict_num(const LaunchCtx& c, const int* list, int count, int width) 
         hipLaunchKernelGGL(k_dict_num<uint32_t>, dim3(gx, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out,
                            c.scratch);
     }
+}
+void launch_dict_slice(const LaunchCtx& c, const int* list, int count, int width) {
+    if (count <= 0 || !c.slice || c.dict_only) return;
+    const unsigned gx = IXR_PACK_TILES / 4;
+    if (width == 64) hipLaunchKernelGGL(k_dict_slice<uint64_t>, dim3(gx, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+    else hipLaunchKernelGGL(k_dict_slice<uint32_t>, dim3(gx, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
 }
 void launch_copy_raw(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;

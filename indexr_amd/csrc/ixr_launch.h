@@ -18,6 +18,7 @@ struct LaunchCtx {
     uint8_t* out;          // output arena
     uint8_t* scratch;      // scratch base of the current group
     int dict_only = 0;     // 1: build dictionaries only; packs whose decode writes straight to the output arena are skipped
+    int slice = 0;         // 1: sorted numeric dictionaries whose rows take them in order are not materialised (k_dict_slice)
     int lane_walk_from = 0;  // framing walk: packs per launch from which one lane (not one wave) follows a stream; 0 = default
 };
 
@@ -33,18 +34,19 @@ struct SmallDesc {  // same layout as ixr_pack_desc
 };
 struct StaticBatch {
     SmallDesc d[kStaticMaxPacks];
+    uint64_t dict_cap;  // bytes reserved for every pack's dictionary; 0: what the pack's rows can hold (see pack_scratch_layout)
     int32_t n;
 };
 // Lays the batch out behind the header; fills `packs` (offsets relative to the block's start + kStaticHeader), the work lists
 // (`lists[c * kStaticMaxPacks + k]`) and their lengths when the pointers are given.  Returns the bytes of the block the batch
 // needs.  Runs on the host (bound check, grid sizes) and on the device (the records themselves) with the same result.
-__host__ __device__ inline uint64_t static_layout(const SmallDesc* d, int n, DevPack* packs, int* lists, int* counts) {
+__host__ __device__ inline uint64_t static_layout(const SmallDesc* d, int n, uint64_t dict_cap, DevPack* packs, int* lists, int* counts) {
     uint64_t index_total = 0;
     for (int i = 0; i < n; i++) {
         DevPack p;
         p.obj_count = d[i].obj_count; p.data_size = d[i].data_size; p.encode_type = d[i].encode_type;
         p.width = (d[i].data_type == 1 || d[i].data_type == 3) ? 32 : (d[i].data_type == 5 ? 0 : 64);
-        index_total += pack_scratch_layout(p, 0).index;
+        index_total += pack_scratch_layout(p, dict_cap).index;
     }
     index_total = scratch_align16(index_total) + 64;  // the bulk area never starts at offset 0 (k_str_copy may read 15 bytes before a dictionary)
     uint64_t io = 0, bo = index_total;
@@ -55,7 +57,7 @@ __host__ __device__ inline uint64_t static_layout(const SmallDesc* d, int n, Dev
         p.obj_count = d[i].obj_count; p.encode_type = d[i].encode_type; p.data_type = d[i].data_type;
         p.width = (d[i].data_type == 1 || d[i].data_type == 3) ? 32 : (d[i].data_type == 5 ? 0 : 64);
         p.ds_off = 0;
-        const ScratchNeed need = pack_scratch_layout(p, 0);
+        const ScratchNeed need = pack_scratch_layout(p, dict_cap);
         if (p.encode_type != 0) {
             p.s_idx[0] += io; p.s_idx[1] += io; p.s_restart += io;
             p.s_dict += bo; p.s_lens += bo; p.s_rows += bo;
@@ -69,7 +71,9 @@ __host__ __device__ inline uint64_t static_layout(const SmallDesc* d, int n, Dev
             counts[SL_ALL]++; counts[c]++;
         }
     }
-    return kStaticHeader + bo + 64;
+    // the same spare bytes behind the last array as a plan's scratch allocation has: kernels read up to 32 bytes past a
+    // dictionary and 16 past a window
+    return kStaticHeader + bo + 64 + 256;
 }
 void launch_static_setup(hipStream_t stream, const StaticBatch& batch, uint8_t* block);
 void launch_export_status(hipStream_t stream, const PackMeta* metas, int count, int32_t* d_status);
@@ -81,6 +85,7 @@ int32_t set_error(int32_t code, const char* message);
 void launch_parse(const LaunchCtx& c, const int* list, int count);
 void launch_delta(const LaunchCtx& c, const int* list, int count, int width, int streams);
 void launch_dict_num(const LaunchCtx& c, const int* list, int count, int width);
+void launch_dict_slice(const LaunchCtx& c, const int* list, int count, int width);  // the packs k_delta marked `sliced`
 void launch_copy_raw(const LaunchCtx& c, const int* list, int count);
 void launch_str_dict_scan(const LaunchCtx& c, const int* list, int count);
 void launch_front_serial(const LaunchCtx& c, const int* list, int count);

@@ -90,6 +90,7 @@ _sig = {
     "ixr_init": (_i32, [_i32]),
     "ixr_last_error": (C.c_char_p, []),
     "ixr_device_count": (_i32, []),
+    "ixr_debug_switch": (_i32, [C.c_char_p, _i32]),
     "ixr_dev_alloc": (_vp, [_i32, _u64]),
     "ixr_dev_free": (None, [_i32, _vp]),
     "ixr_host_alloc_pinned": (_vp, [_u64]),
@@ -141,6 +142,13 @@ for _name, (_res, _args) in _sig.items():
     _fn.argtypes = _args
 
 EXPORTED_SYMBOLS = sorted(_sig)
+
+
+def debug_switch(name, value):
+    """ixr_debug_switch: A/B switches of the library ("split_str", "lane_walk_from"); they apply to plans created afterwards"""
+    rc = lib.ixr_debug_switch(name.encode(), int(value))
+    if rc:
+        raise IxrError(rc, "ixr_debug_switch(%s)" % name)
 
 
 def _ptr(a):

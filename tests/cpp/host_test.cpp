@@ -5,6 +5,7 @@
 //   host_test --gpu <tmpdir>   the decode path on the device: DataPack life cycle, DictStruct, batch, segment scan, errors,
 //                              pack filters (PackExtIndex) and the batch encoder
 // The CPU oracle (oracle/) is linked here as the checker only.
+#include <chrono>
 #include <cinttypes>
 #include <cstdio>
 #include <limits>
@@ -267,6 +268,66 @@ static void test_dict_struct_and_errors(VersionAdapter& va) {
     half.packSize = (int32_t)cut.size();
     CHECK_THROWS(va.decompressPack(VERSION, ColumnType::INT, half, cut), "ixr_decode_pack failed");
 }
+// DataPack.decompress in the reference's own order of calls (DataPack.java:166-186) on full 65536-row packs of all five
+// types: dictionary packs take getDictStruct + getDataFromDictStruct, the others decompressPack; rows and DictStruct are
+// compared with the oracle's, and the time of the calls is printed beside the oracle's for the same packs.
+static void test_datapack_order_full_packs(VersionAdapter& va) {
+    const int kinds[7] = {IXR_COL_I_CAT, IXR_COL_I_SEQ, IXR_COL_L_TS, IXR_COL_F_CARD, IXR_COL_D_CARD, IXR_COL_S_URL, IXR_COL_S_CAT};
+    const char* names[7] = {"i_cat", "i_seq", "l_ts", "f_card", "d_card", "s_url", "s_cat"};
+    for (int ci = 0; ci < 7; ci++) {
+        const uint8_t dt = (uint8_t)ixr_synth_data_type(kinds[ci]);
+        double gpu_ms = 0, cpu_ms = 0;
+        int dict_packs = 0;
+        const int reps = 6;
+        for (int k = 0; k < reps; k++) {
+            const int rows = k == reps - 1 ? 16960 : 65536;
+            std::vector<uint8_t> buf((size_t)rows * 100 + 64);
+            const int32_t sz = ixr_synth_column(kinds[ci], 0xC0FFEE, (uint32_t)k, rows, buf.data(), (int32_t)buf.size());
+            CHECK(sz > 0);
+            if (sz <= 0) return;
+            DataPackNode dpn;
+            dpn.objCount = rows;
+            dpn.dataSize = sz;
+            DataPack p(ByteSlice::copyOf(buf.data(), (size_t)sz), ByteSlice(), dpn);
+            p.compress(va, VERSION, dt, false);
+            DataPack q(ByteSlice(), ByteSlice::copyOf(p.cmpData().address(), p.cmpData().size()), p.dpn());
+            const auto t0 = std::chrono::steady_clock::now();
+            q.decompress(va, VERSION, dt);
+            const auto t1 = std::chrono::steady_clock::now();
+            CHECK(same(q.data(), p.data()));
+            // the oracle's calls in the same order
+            const auto t2 = std::chrono::steady_clock::now();
+            ByteSlice orows = ByteSlice::allocateDirect((size_t)sz);
+            std::vector<uint8_t> ods;
+            if (p.dpn().isDictEncoded()) {
+                int32_t dss = 0;
+                std::memcpy(&dss, p.cmpData().address(), 4);
+                ods.resize((size_t)dss);
+                const int c1 = ixo_get_dict_struct(dt, rows, p.cmpData().address(), (int)p.cmpData().size(), ods.data(), dss);
+                CHECK(c1 == p.dpn().packSize);
+                const int c2 = ixo_data_from_dict_struct(dt, rows, ods.data(), dss, orows.address(), sz);
+                CHECK(c2 >= 0);
+                dict_packs++;
+            } else {
+                const int c = ixo_decompress_pack(dt, p.dpn().encodeType, rows, p.cmpData().address(), (int)p.cmpData().size(), orows.address(), sz);
+                CHECK(c == p.dpn().packSize);
+            }
+            const auto t3 = std::chrono::steady_clock::now();
+            CHECK(same(orows, q.data()));
+            if (p.dpn().isDictEncoded()) {
+                const ByteSlice& ds = q.dictStruct(va, VERSION, dt);
+                CHECK(ds.size() == ods.size() && std::memcmp(ds.address(), ods.data(), ods.size()) == 0);
+            }
+            if (k > 0 && k < reps - 1) {  // the first call of a kind warms the context up, the last is the short pack
+                gpu_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
+                cpu_ms += std::chrono::duration<double, std::milli>(t3 - t2).count();
+            }
+        }
+        std::printf("DataPack.decompress order, %-6s (%s): %.3f ms per full pack through the C ABI, oracle on one core %.3f ms\n", names[ci],
+                    dict_packs ? "getDictStruct + getDataFromDictStruct" : "decompressPack", gpu_ms / (reps - 2), cpu_ms / (reps - 2));
+    }
+}
+
 static void test_segment_scan_gpu(VersionAdapter& va, const std::string& dir) {
     Config1 c = build_config1(va);
     const std::string path = dir + "/config1_gpu.ixrseg";
@@ -509,6 +570,7 @@ int main(int argc, char** argv) {
             test_pack_literals(va, false);
             test_pack_literals(va, true);
             test_dict_struct_and_errors(va);
+            test_datapack_order_full_packs(va);
             test_segment_scan_gpu(va, dir);
             test_ext_index_gpu(va);
             test_encode_batch_gpu(va);

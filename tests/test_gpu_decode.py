@@ -353,12 +353,12 @@ def test_lane_walk_agrees_with_window_walk_on_corrupted_packs():
     plan.destroy()
     filler = base[0]
     big = cases + [filler] * 2000
-    os.environ["IXR_LANE_WALK_FROM"] = "1"  # read when a plan is created: this plan takes the lane walker whatever its size
+    L.debug_switch("lane_walk_from", 1)  # looked at when a plan is created: this plan takes the lane walker whatever its size
     try:
         outs_b, status_b, plan = run_batch(big)
         plan.destroy()
     finally:
-        os.environ.pop("IXR_LANE_WALK_FROM", None)
+        L.debug_switch("lane_walk_from", 0)
     assert len({int(x) for x in status_a}) > 3  # clean packs and more than one kind of failure
     for i, c in enumerate(cases):
         assert status_a[i] == status_b[i], (c.name, status_a[i], status_b[i])

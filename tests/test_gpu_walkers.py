@@ -29,12 +29,12 @@ def three_ways(cases):
             ("lane walker", cases, "1")]
     for label, batch, lanes in runs:
         if lanes:
-            os.environ["IXR_LANE_WALK_FROM"] = lanes
+            L.debug_switch("lane_walk_from", int(lanes))
         try:
             outs, status, plan = run_batch(batch)
             plan.destroy()
         finally:
-            os.environ.pop("IXR_LANE_WALK_FROM", None)
+            L.debug_switch("lane_walk_from", 0)
         for c, out, st in zip(batch, outs, status):
             if c.expect is None:
                 assert st < 0, "%s, %s: the oracle rejects this pack, the GPU returned %d" % (label, c.name, st)
