@@ -104,7 +104,7 @@ struct StrBuilder {  // StringsStruct: int32 offset[n+1] | bodies
         size_t total = off.size() * 4 + body.size();
         if (total > (size_t)cap) return IXR_ERR_BUFFER_OVERFLOW;
         memcpy(out, off.data(), off.size() * 4);
-        memcpy((uint8_t*)out + off.size() * 4, body.data(), body.size());
+        if (!body.empty()) memcpy((uint8_t*)out + off.size() * 4, body.data(), body.size());  // an all-empty column has no body
         return (int32_t)total;
     }
 };

@@ -7,7 +7,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+LIB_PATH = os.environ.get("IXO_LIB") or os.path.join(ORACLE_DIR, "liboracle.so")  # IXO_LIB: another build (sanitizers)
 
 INT, LONG, FLOAT, DOUBLE, STRING = 1, 2, 3, 4, 5
 PLAIN, DELTA, RLE, SIMPLE_DICT, DICT, DICT_COMPRESS = 1, 2, 3, 4, 5, 6

@@ -1,0 +1,201 @@
+// ubench_bridge.hip -- from "rows gathered out of L2 and stored at the rate of plain stores" to the chunk loop of the
+// string kernel, one ingredient at a time (not part of the library).  Every variant writes the same kind of output -- rows
+// of a dictionary laid end to end, produced as 16-byte aligned chunks with one 16-byte gather per chunk -- and is timed on
+// 64 M rows; what differs is named by the flags:
+//   WAVE_TILES   a wave owns a tile of 1024 rows (two passes of 512) instead of a workgroup owning 64 KB of output
+//   LDS_DLT      the rows' source positions are read from a table in LDS (built per pass) instead of computed
+//   SEARCH       the row of a chunk is found by a 9-step binary search in the LDS offsets instead of by division
+//   VARLEN       rows of 20..80 bytes (mean 50) instead of 48: chunks straddle rows
+//   STRADDLE     chunks that straddle rows gather the following rows too (the merge loop)
+//   MANY_DICTS   every pack of 64 tiles has its own 548 KB dictionary and all blocks of a pack sit on one XCD,
+//                instead of one 1 MB dictionary for everything
+//   IDS          the source position of a row comes from doff[id] with the 16-bit ids streamed from memory (2 bytes a row)
+//   OCC6         at most 6 waves per SIMD (the string kernel's launch bound) and its 8 KB of LDS per wave
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_nt(uint8_t* p, uint4 w) { u32x4 t = {w.x, w.y, w.z, w.w}; __builtin_nontemporal_store(t, (u32x4*)p); }
+__device__ __forceinline__ uint4 ld16u(const uint8_t* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
+__device__ __forceinline__ uint64_t low_bytes(int x) { x = max(x, 0); return x >= 8 ? ~0ull : ((1ull << (8 * x)) - 1ull); }
+__device__ __forceinline__ uint32_t hash32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+template <typename U> __device__ __forceinline__ U wave_incl_scan(U v) {
+    for (int d = 1; d < 64; d <<= 1) { U t = __shfl_up(v, d); if ((int)(threadIdx.x & 63) >= d) v += t; }
+    return v;
+}
+enum { WAVE_TILES = 1, LDS_DLT = 2, SEARCH = 4, VARLEN = 8, STRADDLE = 16, MANY_DICTS = 32, IDS = 64, OCC6 = 128 };
+constexpr uint32_t kDictBytes = 548 * 1024, kDictEntries = 11000, kTileRows = 1024, kPassRows = 512;
+
+// block-organised baseline: a workgroup writes 64 KB of 48-byte rows, chunk -> row by division, position hashed
+__global__ __launch_bounds__(256) void k_block(const uint8_t* __restrict__ dict, uint8_t* __restrict__ out, uint32_t dict_bytes) {
+    uint8_t* o = out + (size_t)blockIdx.x * 65536;
+    for (uint32_t i0 = threadIdx.x; i0 < 4096; i0 += 1024) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t c = i0 + 256 * u, row = blockIdx.x * 1366 + c / 3;
+            v[u] = ld16u(dict + hash32(row) % (dict_bytes - 128) + (c % 3) * 16);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) st_nt(o + (size_t)(i0 + 256 * u) * 16, v[u]);
+    }
+}
+
+template <int F>
+__global__ __launch_bounds__(256, (F & OCC6) ? 6 : 1) void k_tiles(const uint8_t* __restrict__ dicts, const uint32_t* __restrict__ doffs,
+                                                                  const uint16_t* __restrict__ ids, uint8_t* __restrict__ out,
+                                                                  uint32_t npacks, uint32_t pack_out_stride) {
+    constexpr uint32_t kWaveLds = (F & OCC6) ? 8192 : 4 * (kPassRows + 4) * 2;
+    __shared__ __align__(16) uint8_t smem[4][kWaveLds];
+    // grid (16, packs); with MANY_DICTS all blocks of a pack share one XCD (linear ids equal mod 8)
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    if (F & MANY_DICTS) {
+        const uint32_t gx = gridDim.x, L = blockIdx.y * gx + blockIdx.x, full = npacks & ~7u;
+        if (L < full * gx) { const uint32_t xcd = L & 7u, sidx = L >> 3; by = (sidx / gx) * 8u + ((xcd + sidx / gx) & 7u); bx = sidx % gx; }
+    }
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tile = bx * 4 + wave, pack = by;
+    const uint8_t* dict = (F & MANY_DICTS) ? dicts + (size_t)pack * (kDictBytes + 256) : dicts;
+    const uint32_t dict_span = (F & MANY_DICTS) ? kDictBytes : (1u << 20);
+    const uint32_t* doff = doffs + ((F & MANY_DICTS) ? (size_t)pack * (kDictEntries + 8) : 0);
+    uint32_t* s_off = (uint32_t*)smem[wave];
+    uint32_t* s_dlt = s_off + kPassRows + 4;
+    uint8_t* obase = out + (size_t)pack * pack_out_stride + (size_t)tile * (kTileRows * 50 + 1024);  // every tile has its own stretch
+    uint32_t run = 0;
+    for (uint32_t pass = 0; pass < kTileRows / kPassRows; pass++) {
+        // ---- the pass's rows: lengths, offsets (scan), source positions; four neighbouring rows per lane
+        const uint32_t row0 = (pack * 64 + tile) * kTileRows + pass * kPassRows;
+#pragma unroll
+        for (uint32_t q = 0; q < kPassRows / 256; q++) {
+            const uint32_t rl = q * 256 + 4 * lane;
+            uint32_t len[4], src[4], ex[4], s4 = 0;
+            uint2 four = make_uint2(0, 0);
+            if (F & IDS) four = *(const uint2*)(ids + row0 + rl);
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const uint32_t h = hash32(row0 + rl + g);
+                if (F & IDS) {
+                    const uint32_t id = (((g < 2 ? four.x : four.y) >> (16 * (g & 1))) & 0xFFFFu) % kDictEntries;
+                    uint2 ab; __builtin_memcpy(&ab, doff + id, 8);
+                    src[g] = ab.x; len[g] = (F & VARLEN) ? ab.y - ab.x : 48u;
+                } else {
+                    len[g] = (F & VARLEN) ? 20u + h % 61u : 48u;
+                    src[g] = (h >> 8) % (dict_span - 128u);
+                }
+                ex[g] = s4; s4 += len[g];
+            }
+            const uint32_t inc = wave_incl_scan(s4), first = run + inc - s4;
+            run += __shfl(inc, 63);
+            *(uint4*)(s_off + rl) = make_uint4(first + ex[0], first + ex[1], first + ex[2], first + ex[3]);
+            *(uint4*)(s_dlt + rl) = make_uint4(src[0] - first - ex[0], src[1] - first - ex[1], src[2] - first - ex[2], src[3] - first - ex[3]);
+        }
+        if (lane == 0) s_off[kPassRows] = run;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t b0 = s_off[0], b1 = s_off[kPassRows];
+        for (uint32_t c0 = (b0 & ~15u) + 16u * lane; c0 < b1; c0 += 4 * 1024u) {
+            uint32_t cp[4], rr[4];
+            uint4 w[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                cp[u] = c0 + u * 1024u < b1 ? c0 + u * 1024u : c0;
+                const uint32_t first = max(cp[u], b0);
+                uint32_t r = 0;
+                if (F & SEARCH) {
+#pragma unroll
+                    for (uint32_t step = kPassRows / 2; step >= 1; step >>= 1) {
+                        const uint32_t c = r + step, o = s_off[min(c, kPassRows)];
+                        if (c < kPassRows && o <= first) r = c;
+                    }
+                } else {
+                    r = min(kPassRows - 1, (first - b0) / 48u);  // rows of 48 bytes in every variant without the search
+                }
+                rr[u] = r;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                // a chunk may start up to 15 bytes before its row does: the position is signed (the dictionaries start 64
+                // bytes into their allocation)
+                int32_t sp;
+                if (F & LDS_DLT) sp = (int32_t)(s_dlt[rr[u]] + cp[u]);
+                else sp = (int32_t)((hash32(row0 + rr[u]) >> 8) % (dict_span - 128u) + (cp[u] & 31u));
+                w[u] = ld16u(dict + 64 + (ptrdiff_t)sp);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (c0 + u * 1024u >= b1) continue;
+                uint4 v = w[u];
+                const uint32_t cpos = cp[u], cend = min(cpos + 16u, b1);
+                if (F & STRADDLE) {
+                    uint32_t r = rr[u], rend = s_off[r + 1], pos = min(cend, rend);
+                    if (pos < cend) {
+                        uint64_t wl = (uint64_t)v.x | ((uint64_t)v.y << 32), wh = (uint64_t)v.z | ((uint64_t)v.w << 32);
+                        while (pos < cend) {
+                            do { r++; rend = s_off[r + 1]; } while (rend <= pos && r + 1 < kPassRows);
+                            const uint32_t segend = min(cend, max(rend, pos + 1));
+                            const uint4 x = ld16u(dict + 64 + (ptrdiff_t)(int32_t)(s_dlt[r] + cpos));
+                            const int a = (int)(pos - cpos), e = (int)(segend - cpos);
+                            const uint64_t ml = low_bytes(e) & ~low_bytes(a), mh = low_bytes(e - 8) & ~low_bytes(a - 8);
+                            wl = (wl & ~ml) | (((uint64_t)x.x | ((uint64_t)x.y << 32)) & ml);
+                            wh = (wh & ~mh) | (((uint64_t)x.z | ((uint64_t)x.w << 32)) & mh);
+                            pos = segend;
+                        }
+                        v = make_uint4((uint32_t)wl, (uint32_t)(wl >> 32), (uint32_t)wh, (uint32_t)(wh >> 32));
+                    }
+                }
+                st_nt(obase + cpos, v);  // whole chunks everywhere: the edges of a pass overlap by design here
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int main() {
+    const uint32_t npacks = 1024;  // x 64 tiles x 1024 rows = 64 M rows, ~3.3 GB of rows
+    const size_t dict_total = (size_t)npacks * (kDictBytes + 256) + (2u << 20);
+    uint8_t* dicts; CK(hipMalloc(&dicts, dict_total)); CK(hipMemset(dicts, 7, dict_total));
+    std::vector<uint32_t> hdoff((size_t)npacks * (kDictEntries + 8));
+    for (uint32_t p = 0; p < npacks; p++) {
+        uint32_t pos = 0;
+        for (uint32_t i = 0; i <= kDictEntries + 7; i++) { hdoff[(size_t)p * (kDictEntries + 8) + i] = pos; if (i < kDictEntries) pos += 20 + (i * 2654435761u >> 7) % 61; }
+    }
+    uint32_t* doffs; CK(hipMalloc(&doffs, hdoff.size() * 4)); CK(hipMemcpy(doffs, hdoff.data(), hdoff.size() * 4, hipMemcpyHostToDevice));
+    const size_t nrows = (size_t)npacks * 64 * kTileRows;
+    std::vector<uint16_t> hids(nrows + 64);
+    uint64_t x = 88172645463325252ull;
+    for (auto& v : hids) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = (uint16_t)(x % kDictEntries); }
+    uint16_t* ids; CK(hipMalloc(&ids, hids.size() * 2)); CK(hipMemcpy(ids, hids.data(), hids.size() * 2, hipMemcpyHostToDevice));
+    const uint32_t pack_out_stride = 64 * (kTileRows * 50 + 1024) + 65536;
+    const size_t out_bytes = (size_t)npacks * pack_out_stride + (1u << 20);
+    uint8_t* out; CK(hipMalloc(&out, out_bytes)); CK(hipMemset(out, 0, out_bytes));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto timeit = [&](const char* name, double bytes, auto fn) {
+        fn(); (void)hipDeviceSynchronize();
+        float best = 1e9;
+        for (int it = 0; it < 5; it++) {
+            (void)hipEventRecord(e0); fn(); (void)hipEventRecord(e1);
+            if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) { printf("%s failed\n", name); exit(1); }
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+        }
+        printf("%-86s %8.3f ms  %8.1f GB/s of rows\n", name, best, bytes / 1e9 / (best / 1e3));
+    };
+    const double fixed_bytes = (double)nrows * 48, var_bytes = (double)nrows * 50;
+    timeit("workgroup owns 64 KB: 48-byte rows, position hashed, one 1 MB dictionary", 65536.0 * 50000,
+           [&] { hipLaunchKernelGGL(k_block, dim3(50000), dim3(256), 0, 0, dicts, out, 1u << 20); });
+#define RUN(F, bytes, name) timeit(name, bytes, [&] { hipLaunchKernelGGL((k_tiles<(F)>), dim3(16, npacks), dim3(256), 0, 0, dicts, doffs, ids, out, npacks, pack_out_stride); })
+    RUN(WAVE_TILES, fixed_bytes, "wave owns a 1024-row tile (48-byte rows, row by division, position hashed)");
+    RUN(WAVE_TILES | LDS_DLT, fixed_bytes, "+ source position from the LDS table");
+    RUN(WAVE_TILES | LDS_DLT | SEARCH, fixed_bytes, "+ 9-step row search in LDS");
+    RUN(WAVE_TILES | LDS_DLT | SEARCH | OCC6, fixed_bytes, "+ 6 waves per SIMD at most, 8 KB of LDS per wave");
+    RUN(WAVE_TILES | LDS_DLT | SEARCH | OCC6 | VARLEN, var_bytes, "+ rows of 20..80 bytes (straddling chunks take their first row's bytes only)");
+    RUN(WAVE_TILES | LDS_DLT | SEARCH | OCC6 | VARLEN | STRADDLE, var_bytes, "+ the straddle loop (gathers of the following rows, byte masks)");
+    RUN(WAVE_TILES | LDS_DLT | SEARCH | OCC6 | VARLEN | STRADDLE | MANY_DICTS, var_bytes, "+ one 548 KB dictionary per pack, a pack's blocks on one XCD");
+    RUN(WAVE_TILES | LDS_DLT | SEARCH | OCC6 | VARLEN | STRADDLE | MANY_DICTS | IDS, var_bytes, "+ positions from doff[id], ids streamed (2 bytes a row)");
+    RUN(WAVE_TILES | LDS_DLT | SEARCH | OCC6 | VARLEN | STRADDLE | IDS, var_bytes, "  the same with ONE dictionary for all packs");
+    RUN(WAVE_TILES | LDS_DLT | SEARCH | OCC6 | VARLEN | MANY_DICTS | IDS, var_bytes, "  the same without the straddle loop");
+    RUN(WAVE_TILES | LDS_DLT | SEARCH | VARLEN | STRADDLE | MANY_DICTS | IDS, var_bytes, "  the same without the occupancy bound");
+    return 0;
+}
