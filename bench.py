@@ -30,7 +30,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak; measured on this pool: a plain copy kernel moves 4.8 TB/s (read + written), stores alone 5.5-5.8 TB/s
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak; measured on this pool (tools/ubench_peak.hip): a plain copy moves 6.2 TB/s (read + written), reads alone 6.4 TB/s, stores alone 5.5 TB/s
 
 WORKLOADS = {
     # name: (description, column kinds)
@@ -411,22 +411,25 @@ def pmc_traffic(kernel, workload, launches_per_pass, n_packs):
     are None unless the file was measured on this very workload AND on these very kernel sources: the file carries a
     hash of indexr_amd/csrc, and a counter file of other kernels says nothing about the ones that just ran."""
     from indexr_amd import provenance
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        with open(path) as fh:
-            doc = json.load(fh)
-    except (OSError, ValueError):
-        return None, None, None
-    # one GPU's counters: the same column mix and pack count, whatever the file's run called its sharding
-    if doc.get("csrc_hash") != provenance.csrc_hash() or doc.get("packs") != n_packs or \
-            str(doc.get("workload", "")).split(",")[0] != workload.split(",")[0]:
-        return None, None, None
-    k = doc.get("kernels", {}).get(kernel)
-    if not k or not k.get("hbm_bytes_per_pass") or launches_per_pass <= 0:
-        return None, None, None
-    total = sum(v.get("hbm_bytes_per_pass") or 0 for v in doc["kernels"].values())
-    # the counters were summed over one pass of the table; this run may split the pass into a different number of launches
-    return int(k["hbm_bytes_per_pass"] / launches_per_pass), "profiles/pmc_traffic.json (%s)" % doc.get("source", ""), int(total)
+    import glob
+    # one file per workload: profiles/pmc_traffic.json (the mixed table of the headline), pmc_traffic_<workload>.json
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_traffic*.json"))):
+        try:
+            with open(path) as fh:
+                doc = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        # one GPU's counters: the same column mix and pack count, whatever the file's run called its sharding
+        if doc.get("csrc_hash") != provenance.csrc_hash() or doc.get("packs") != n_packs or \
+                str(doc.get("workload", "")).split(",")[0] != workload.split(",")[0]:
+            continue
+        k = doc.get("kernels", {}).get(kernel)
+        if not k or not k.get("hbm_bytes_per_pass") or launches_per_pass <= 0:
+            continue
+        total = sum(v.get("hbm_bytes_per_pass") or 0 for v in doc["kernels"].values())
+        # the counters were summed over one pass of the table; this run may split the pass into a different number of launches
+        return int(k["hbm_bytes_per_pass"] / launches_per_pass), "profiles/%s (%s)" % (os.path.basename(path), doc.get("source", "")), int(total)
+    return None, None, None
 
 
 def plan_only(args, T, dist, tdev, world, rank, scaling, ranges, mine, table, n_packs, real_stdout):
