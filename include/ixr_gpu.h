@@ -142,9 +142,13 @@ int32_t   ixr_plan_kernel_bytes(ixr_plan* plan, uint64_t* alg_bytes, int32_t cap
  * scratch_budget_bytes: a smaller budget gives more, smaller groups) go through two device staging buffers per direction:
  * the copy in of group g+1, the decode of group g and the copy out of group g-1 run at the same time on three streams of
  * the plan's own.  The call returns when all rows are in h_out; ixr_plan_status(plan, status, NULL) then reports per pack.
- * Both arenas should be pinned (ixr_host_alloc_pinned): pageable memory works, without the overlap.  The packs must lie
- * in plan order in the output arena; the (at most 15) alignment bytes between two packs' rows are overwritten with
- * unspecified values.  The staging buffers, sized for the largest group, stay with the plan until it is destroyed. */
+ * Both arenas should be pinned (ixr_host_alloc_pinned): pageable memory works, without the overlap.  A group's rows travel
+ * back as ONE copy of the stretch of the output arena its packs span, so the packs must lie in plan order and, within a
+ * group, back to back in the output arena: at most the 15 alignment bytes between two packs' rows (those bytes are
+ * overwritten with unspecified values); in the input arena gaps of up to 4096 bytes are accepted.  Any other layout is
+ * refused with IXR_ERR_INVALID_ARGUMENT before anything is copied (ixr_plan_run takes it).  On any error the call returns
+ * only after the copies it has started have ended.  The staging buffers, sized for the largest group, stay with the plan
+ * until it is destroyed. */
 int32_t   ixr_plan_run_host(ixr_plan* plan, const void* h_in, uint64_t in_bytes, void* h_out, uint64_t out_bytes);
 
 /* ---- batch decode that allocates nothing ----------------------------------------------------------------------------
@@ -185,6 +189,13 @@ int32_t   ixr_plan_run_dict_structs(ixr_plan* plan, const void* d_in, uint64_t i
  * Same contract as the reference's Decoder.decodeInts|Longs|Floats|Doubles|Strings(valCount, inputAddr, outputAddr,
  * outputLimit) (Decoder.java:5-25) dispatched like PackCompressor_VLT.decompress (:130-170).  Copies the pack to the
  * device, decodes it there, copies the result back.  Meant for parity tests and small callers; engines should batch.
+ * All three calls work out of a per-device pool of contexts (a stream, device and pinned staging buffers, a working block of
+ * IXR_STATIC_SCRATCH_BYTES): a call allocates nothing once a context exists, any number of threads may call at once (each takes
+ * a context of its own), and the calling thread POLLS its stream for up to one millisecond before it falls back to a blocking
+ * wait (a decode takes tens to hundreds of microseconds; a blocking wait's wake-up alone can take longer), so a call occupies
+ * its host core for its whole duration.  At most 8 idle contexts per device are kept until the process ends (about 34 MiB of
+ * device memory and 2 MiB of pinned memory each; buffers that a large pack grew beyond 16 MiB are released after the call).
+ * A pack whose working arrays exceed the block (very long strings) takes a one-pack plan instead, with its allocations.
  */
 int32_t ixr_decode_pack(int32_t device, int32_t data_type, int32_t encode_type, int32_t obj_count,
                         const void* in, int32_t in_size, void* out, int32_t out_limit);
