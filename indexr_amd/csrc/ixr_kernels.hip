@@ -137,6 +137,45 @@ __device__ __forceinline__ uint32_t pack_slot_remap(uint32_t b, uint32_t count) 
     return b < (count & ~7u) ? (b & ~7u) + xcd_slot(b >> 3, b & 7u) : b;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Warming the XCD's L2 with a pack's dictionary.  The row kernels gather from the decoded dictionary in scratch, which an
+// earlier kernel wrote and which has left the caches since (a group's dictionaries are a gigabyte).  The vector L1 of a
+// compute unit returns its loads in order: a gather that has to go to memory holds back every cache hit queued behind it,
+// so it pays to have the lines in L2 before the gathers ask for them.  All workgroups of a pack run on one XCD
+// (pack_block_remap); each touches ONE dword of every 128-byte line of its share of the dictionary when it starts, with all
+// loads issued before anything waits, and throws the data away.  Measured on the string kernel's loop (tools/ubench_bridge.hip,
+// Zipf-distributed ids, 548 KB dictionaries): 1.90 -> 1.55 ms; one 16-byte load per lane and piece instead: 1.65.
+// ---------------------------------------------------------------------------------------------------------------
+#ifdef IXR_NO_WARM  // build switch for A/B timing
+constexpr bool kWarm = false;
+#else
+constexpr bool kWarm = true;
+#endif
+constexpr uint32_t kWarmLoads = 3;            // per lane: 256 lanes x 3 lines x 128 bytes = 96 KB per workgroup, 1.5 MB per pack of 16 workgroups
+constexpr uint32_t kWarmMinBytes = 32768;     // smaller dictionaries come along with the first gathers
+struct Warm { uint32_t v[kWarmLoads]; };
+// [d0, d0 + bytes) must be readable up to the next multiple of 4 (d0 is 4-byte aligned); `part` of `parts` is this workgroup's
+// share.  A dictionary whose entries are used about once each (as many entries as rows: unique values, sorted columns) is
+// not warmed: every line is fetched once either way, and the extra loads only cost (measured: unique strings 1.39 -> 1.46 ms).
+__device__ __forceinline__ Warm warm_issue(const uint8_t* d0, uint32_t bytes, uint32_t part, uint32_t parts, uint32_t entries, uint32_t rows) {
+    Warm w;
+#pragma unroll
+    for (uint32_t k = 0; k < kWarmLoads; k++) w.v[k] = 0;
+    if (!kWarm || bytes < kWarmMinBytes || 2u * rows < 3u * entries) return w;
+    const uint32_t lines = (bytes + 127u) >> 7, per = (lines + parts - 1u) / parts;
+#pragma unroll
+    for (uint32_t k = 0; k < kWarmLoads; k++) {
+        const uint32_t idx = threadIdx.x + k * 256u, line = part * per + idx;
+        if (idx < per && line < lines) w.v[k] = *(const uint32_t*)(d0 + 128ull * line);  // 128 * line <= bytes - 1: at most 3 bytes past the end
+    }
+    return w;
+}
+__device__ __forceinline__ void warm_done(const Warm& w) {  // the loads must be kept although nothing reads their data
+#pragma unroll
+    for (uint32_t k = 0; k < kWarmLoads; k++) asm volatile("" ::"v"(w.v[k]));
+}
+
 template <uint32_t kW>
 struct WinT {
     static constexpr uint32_t kBytes = kW;                    // bytes of the pack the window can hold
@@ -1351,6 +1390,7 @@ __global__ __launch_bounds__(256) void k_dict_num(const DevPack* __restrict__ pa
     const PackMeta& M = metas[t.pi];
     if (M.sliced) return;              // k_dict_slice takes this pack
     const U* __restrict__ dict = (const U*)(scratch + P.s_dict);
+    const Warm warm = warm_issue(scratch + P.s_dict, t.ec * (uint32_t)sizeof(U), t.tile >> 2, gridDim.x, t.ec, t.n);
     U* __restrict__ dst = (U*)(out + P.out_off) + t.tile_start;
     uint16_t* ids = s_ids[threadIdx.x >> 6];
     const uint4 seg = ((const uint4*)(scratch + P.s_restart))[t.tile];
@@ -1374,6 +1414,7 @@ __global__ __launch_bounds__(256) void k_dict_num(const DevPack* __restrict__ pa
     U v[16];
 #pragma unroll
     for (int q = 0; q < 16; q++) v[q] = dict[id[q]];
+    warm_done(warm);
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         const uint32_t r = q * 128 + 2 * lane;
@@ -2596,6 +2637,9 @@ __global__ __launch_bounds__(256, IXR_FUSED_WAVES_PER_SIMD) void k_str_fused(con
     uint8_t* base16 = body - A;
     const uint32_t tbase = uniform_load((const uint32_t*)(scratch + P.s_rows) + tile);  // offset of the tile's first row
     uint8_t* wl = smem[wave];
+    // this workgroup's share of the dictionary (offsets and bytes; its size was checked against the scratch region by the
+    // dictionary scan) on its way into L2 while the ids are expanded
+    const Warm warm = warm_issue(scratch + P.s_dict, 4u * (ec + 1u) + uniform_load(doff + ec), bx, gridDim.x, ec, n);
 
     // ---- the tile's ids and the rows' dictionary slices
     uint2 ab[16];
@@ -2618,6 +2662,7 @@ __global__ __launch_bounds__(256, IXR_FUSED_WAVES_PER_SIMD) void k_str_fused(con
         }
         FusedWin::wave_lds_sync();  // the id tile and the window are dead: their memory becomes the offset tables
     }
+    warm_done(warm);
     uint32_t* s_off = (uint32_t*)wl;                   // [rows + 1] shifted output offsets of the pass's rows
     uint32_t* s_dlt = (uint32_t*)(wl + kFusedDltOff);  // [rows] srcOff - s_off + 16 (mod 2^32)
     const uint8_t* dbody16 = dbody - 16;  // chunk byte k of row r comes from dbody16[s_dlt[r] + cpos + k]; the sum is >= 1

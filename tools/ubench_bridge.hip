@@ -10,12 +10,25 @@
 //   MANY_DICTS   every pack of 64 tiles has its own 548 KB dictionary and all blocks of a pack sit on one XCD,
 //                instead of one 1 MB dictionary for everything
 //   IDS          the source position of a row comes from doff[id] with the 16-bit ids streamed from memory (2 bytes a row)
-//   OCC6         at most 6 waves per SIMD (the string kernel's launch bound) and its 8 KB of LDS per wave
+//   OCC6         at most 6 waves per SIMD (the string kernel's launch bound)
+// and candidate remedies:
+//   ZIPF         the ids follow a Zipf(1.1) law over the dictionary's entries (hot entries scattered) instead of a uniform one
+//   TRIM         the last step of a pass skips the chunk slots no lane needs (wave-uniform) instead of repeating slot 0
+//   ALIGN128     the chunk grid starts at a multiple of 128 bytes: every store instruction of a wave covers whole lines
+//   TILE256      a wave owns 256 rows (one pass): four times the waves per pack, a quarter of the packs in flight per XCD
+//   NOREMAP      per-pack dictionaries, but the blocks of a pack are dealt over the XCDs as they come (no XCD relabelling)
+//   REMAP1       one dictionary, but with the XCD relabelling
+//   ONE_DOFF     per-pack dictionaries, one offset table for all packs
+//   PREFL        the same warm-up with ONE dword load per 128-byte line (two or three loads per lane instead of nine of 16 bytes)
+//   PREFV        before its tiles, a workgroup streams its share (1/16) of the pack's dictionary through coalesced 16-byte loads
+//                whose data it throws away: the gathers that follow find the lines in the XCD's L2
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
+#include <cmath>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_nt(uint8_t* p, uint4 w) { u32x4 t = {w.x, w.y, w.z, w.w}; __builtin_nontemporal_store(t, (u32x4*)p); }
@@ -26,8 +39,9 @@ template <typename U> __device__ __forceinline__ U wave_incl_scan(U v) {
     for (int d = 1; d < 64; d <<= 1) { U t = __shfl_up(v, d); if ((int)(threadIdx.x & 63) >= d) v += t; }
     return v;
 }
-enum { WAVE_TILES = 1, LDS_DLT = 2, SEARCH = 4, VARLEN = 8, STRADDLE = 16, MANY_DICTS = 32, IDS = 64, OCC6 = 128 };
-constexpr uint32_t kDictBytes = 548 * 1024, kDictEntries = 11000, kTileRows = 1024, kPassRows = 512;
+enum { WAVE_TILES = 1, LDS_DLT = 2, SEARCH = 4, VARLEN = 8, STRADDLE = 16, MANY_DICTS = 32, IDS = 64, OCC6 = 128,
+       ZIPF = 256, TRIM = 512, ALIGN128 = 1024, TILE256 = 2048, PREFV = 4096, NOREMAP = 8192, REMAP1 = 16384, ONE_DOFF = 32768, PREFL = 65536 };
+constexpr uint32_t kDictBytes = 548 * 1024, kDictEntries = 11000;
 
 // block-organised baseline: a workgroup writes 64 KB of 48-byte rows, chunk -> row by division, position hashed
 __global__ __launch_bounds__(256) void k_block(const uint8_t* __restrict__ dict, uint8_t* __restrict__ out, uint32_t dict_bytes) {
@@ -48,25 +62,52 @@ template <int F>
 __global__ __launch_bounds__(256, (F & OCC6) ? 6 : 1) void k_tiles(const uint8_t* __restrict__ dicts, const uint32_t* __restrict__ doffs,
                                                                   const uint16_t* __restrict__ ids, uint8_t* __restrict__ out,
                                                                   uint32_t npacks, uint32_t pack_out_stride) {
-    constexpr uint32_t kWaveLds = (F & OCC6) ? 8192 : 4 * (kPassRows + 4) * 2;
+    constexpr uint32_t kTileRows = (F & TILE256) ? 256 : 1024, kPassRows = (F & TILE256) ? 256 : 512;
+    constexpr uint32_t kTilesPerPack = 65536 / kTileRows;
+    constexpr uint32_t kWaveLds = 4 * (512 + 4) * 2;  // 4128 bytes per wave, as the string kernel has (offsets and deltas of 512 rows)
     __shared__ __align__(16) uint8_t smem[4][kWaveLds];
     // grid (16, packs); with MANY_DICTS all blocks of a pack share one XCD (linear ids equal mod 8)
     uint32_t bx = blockIdx.x, by = blockIdx.y;
-    if (F & MANY_DICTS) {
+    if (((F & MANY_DICTS) && !(F & NOREMAP)) || (F & REMAP1)) {
         const uint32_t gx = gridDim.x, L = blockIdx.y * gx + blockIdx.x, full = npacks & ~7u;
         if (L < full * gx) { const uint32_t xcd = L & 7u, sidx = L >> 3; by = (sidx / gx) * 8u + ((xcd + sidx / gx) & 7u); bx = sidx % gx; }
     }
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tile = bx * 4 + wave, pack = by;
     const uint8_t* dict = (F & MANY_DICTS) ? dicts + (size_t)pack * (kDictBytes + 256) : dicts;
     const uint32_t dict_span = (F & MANY_DICTS) ? kDictBytes : (1u << 20);
-    const uint32_t* doff = doffs + ((F & MANY_DICTS) ? (size_t)pack * (kDictEntries + 8) : 0);
+    const uint32_t* doff = doffs + (((F & MANY_DICTS) && !(F & ONE_DOFF)) ? (size_t)pack * (kDictEntries + 8) : 0);
+    if (F & PREFV) {
+        const uint32_t share = dict_span / gridDim.x & ~15u;  // bytes of the dictionary this workgroup warms up
+        const uint8_t* p0 = dict + 64 + (size_t)bx * share;
+        // all loads are issued before any is waited for (nine cover a sixteenth of 548 KB at 256 lanes x 16 bytes)
+        uint4 v[9];
+#pragma unroll
+        for (uint32_t k = 0; k < 9; k++) {
+            const uint32_t o = threadIdx.x * 16u + k * 4096u;
+            v[k] = *(const uint4*)(p0 + min(o, share - 16u));
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 9; k++) asm volatile("" ::"v"(v[k].x), "v"(v[k].y), "v"(v[k].z), "v"(v[k].w));  // the data is not used
+    }
+    if (F & PREFL) {
+        const uint32_t share = (dict_span / gridDim.x + 127u) & ~127u;
+        const uint8_t* p0 = dict + 64 + (size_t)bx * share;
+        uint32_t v[3];
+#pragma unroll
+        for (uint32_t k = 0; k < 3; k++) {
+            const uint32_t o = (threadIdx.x + k * 256u) * 128u;
+            v[k] = *(const uint32_t*)(p0 + min(o, share - 128u));
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 3; k++) asm volatile("" ::"v"(v[k]));
+    }
     uint32_t* s_off = (uint32_t*)smem[wave];
     uint32_t* s_dlt = s_off + kPassRows + 4;
     uint8_t* obase = out + (size_t)pack * pack_out_stride + (size_t)tile * (kTileRows * 50 + 1024);  // every tile has its own stretch
     uint32_t run = 0;
     for (uint32_t pass = 0; pass < kTileRows / kPassRows; pass++) {
         // ---- the pass's rows: lengths, offsets (scan), source positions; four neighbouring rows per lane
-        const uint32_t row0 = (pack * 64 + tile) * kTileRows + pass * kPassRows;
+        const uint32_t row0 = (pack * kTilesPerPack + tile) * kTileRows + pass * kPassRows;
 #pragma unroll
         for (uint32_t q = 0; q < kPassRows / 256; q++) {
             const uint32_t rl = q * 256 + 4 * lane;
@@ -95,12 +136,16 @@ __global__ __launch_bounds__(256, (F & OCC6) ? 6 : 1) void k_tiles(const uint8_t
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
         const uint32_t b0 = s_off[0], b1 = s_off[kPassRows];
-        for (uint32_t c0 = (b0 & ~15u) + 16u * lane; c0 < b1; c0 += 4 * 1024u) {
+        for (uint32_t c0 = (b0 & ((F & ALIGN128) ? ~127u : ~15u)) + 16u * lane; c0 - 16u * lane < b1; c0 += 4 * 1024u) {
             uint32_t cp[4], rr[4];
             uint4 w[4];
+            // chunk slots this step needs: all four, except in a pass's last step (the same in every lane)
+            const uint32_t c0w = __builtin_amdgcn_readfirstlane(c0 - 16u * lane);
+            const uint32_t nslot = (F & TRIM) ? min(4u, (b1 - c0w + 1023u) / 1024u) : 4u;
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                cp[u] = c0 + u * 1024u < b1 ? c0 + u * 1024u : c0;
+                if ((F & TRIM) && (uint32_t)u >= nslot) { cp[u] = c0; rr[u] = 0; continue; }
+                cp[u] = (c0 + u * 1024u < b1 && c0 + u * 1024u + 16u > b0) ? c0 + u * 1024u : max(c0, b0 & ~15u);
                 const uint32_t first = max(cp[u], b0);
                 uint32_t r = 0;
                 if (F & SEARCH) {
@@ -116,16 +161,18 @@ __global__ __launch_bounds__(256, (F & OCC6) ? 6 : 1) void k_tiles(const uint8_t
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
+                if ((F & TRIM) && (uint32_t)u >= nslot) continue;
                 // a chunk may start up to 15 bytes before its row does: the position is signed (the dictionaries start 64
                 // bytes into their allocation)
                 int32_t sp;
                 if (F & LDS_DLT) sp = (int32_t)(s_dlt[rr[u]] + cp[u]);
                 else sp = (int32_t)((hash32(row0 + rr[u]) >> 8) % (dict_span - 128u) + (cp[u] & 31u));
+                sp = min(max(sp, -48), (int32_t)dict_span + 64);  // belt and braces: whatever the tables say, the gather stays inside the allocation
                 w[u] = ld16u(dict + 64 + (ptrdiff_t)sp);
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                if (c0 + u * 1024u >= b1) continue;
+                if (c0 + u * 1024u >= b1 || c0 + u * 1024u + 16u <= b0) continue;  // past the pass's end, or (aligned grid) before its start
                 uint4 v = w[u];
                 const uint32_t cpos = cp[u], cend = min(cpos + 16u, b1);
                 if (F & STRADDLE) {
@@ -135,7 +182,8 @@ __global__ __launch_bounds__(256, (F & OCC6) ? 6 : 1) void k_tiles(const uint8_t
                         while (pos < cend) {
                             do { r++; rend = s_off[r + 1]; } while (rend <= pos && r + 1 < kPassRows);
                             const uint32_t segend = min(cend, max(rend, pos + 1));
-                            const uint4 x = ld16u(dict + 64 + (ptrdiff_t)(int32_t)(s_dlt[r] + cpos));
+                            const int32_t xp = min(max((int32_t)(s_dlt[r] + cpos), -48), (int32_t)dict_span + 64);
+                            const uint4 x = ld16u(dict + 64 + (ptrdiff_t)xp);
                             const int a = (int)(pos - cpos), e = (int)(segend - cpos);
                             const uint64_t ml = low_bytes(e) & ~low_bytes(a), mh = low_bytes(e - 8) & ~low_bytes(a - 8);
                             wl = (wl & ~ml) | (((uint64_t)x.x | ((uint64_t)x.y << 32)) & ml);
@@ -145,7 +193,7 @@ __global__ __launch_bounds__(256, (F & OCC6) ? 6 : 1) void k_tiles(const uint8_t
                         v = make_uint4((uint32_t)wl, (uint32_t)(wl >> 32), (uint32_t)wh, (uint32_t)(wh >> 32));
                     }
                 }
-                st_nt(obase + cpos, v);  // whole chunks everywhere: the edges of a pass overlap by design here
+                st_nt(obase + min(cpos, 96u * 1024u), v);  // whole chunks everywhere: the edges of a pass overlap by design here
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
@@ -163,12 +211,27 @@ int main() {
         for (uint32_t i = 0; i <= kDictEntries + 7; i++) { hdoff[(size_t)p * (kDictEntries + 8) + i] = pos; if (i < kDictEntries) pos += 20 + (i * 2654435761u >> 7) % 61; }
     }
     uint32_t* doffs; CK(hipMalloc(&doffs, hdoff.size() * 4)); CK(hipMemcpy(doffs, hdoff.data(), hdoff.size() * 4, hipMemcpyHostToDevice));
-    const size_t nrows = (size_t)npacks * 64 * kTileRows;
+    const size_t nrows = (size_t)npacks * 65536;
     std::vector<uint16_t> hids(nrows + 64);
     uint64_t x = 88172645463325252ull;
     for (auto& v : hids) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = (uint16_t)(x % kDictEntries); }
     uint16_t* ids; CK(hipMalloc(&ids, hids.size() * 2)); CK(hipMemcpy(ids, hids.data(), hids.size() * 2, hipMemcpyHostToDevice));
-    const uint32_t pack_out_stride = 64 * (kTileRows * 50 + 1024) + 65536;
+    // the same number of ids drawn from a Zipf(1.1) law over the entries, the hot entries scattered over the dictionary
+    {
+        std::vector<double> cdf(kDictEntries);
+        double acc = 0;
+        for (uint32_t k = 0; k < kDictEntries; k++) { acc += std::pow((double)(k + 1), -1.1); cdf[k] = acc; }
+        std::vector<uint16_t> perm(kDictEntries);
+        for (uint32_t k = 0; k < kDictEntries; k++) perm[k] = (uint16_t)k;
+        for (uint32_t k = kDictEntries - 1; k > 0; k--) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; std::swap(perm[k], perm[x % (k + 1)]); }
+        for (auto& v : hids) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            const double u = (double)(x >> 11) / 9007199254740992.0 * acc;
+            v = perm[(size_t)(std::lower_bound(cdf.begin(), cdf.end(), u) - cdf.begin()) % kDictEntries];
+        }
+    }
+    uint16_t* zids; CK(hipMalloc(&zids, hids.size() * 2)); CK(hipMemcpy(zids, hids.data(), hids.size() * 2, hipMemcpyHostToDevice));
+    const uint32_t pack_out_stride = 256 * (256 * 50 + 1024) + 65536;  // room for either tiling: 64 x 52224 or 256 x 13824 bytes, multiples of 128
     const size_t out_bytes = (size_t)npacks * pack_out_stride + (1u << 20);
     uint8_t* out; CK(hipMalloc(&out, out_bytes)); CK(hipMemset(out, 0, out_bytes));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -185,11 +248,11 @@ int main() {
     const double fixed_bytes = (double)nrows * 48, var_bytes = (double)nrows * 50;
     timeit("workgroup owns 64 KB: 48-byte rows, position hashed, one 1 MB dictionary", 65536.0 * 50000,
            [&] { hipLaunchKernelGGL(k_block, dim3(50000), dim3(256), 0, 0, dicts, out, 1u << 20); });
-#define RUN(F, bytes, name) timeit(name, bytes, [&] { hipLaunchKernelGGL((k_tiles<(F)>), dim3(16, npacks), dim3(256), 0, 0, dicts, doffs, ids, out, npacks, pack_out_stride); })
+#define RUN(F, bytes, name) timeit(name, bytes, [&] { hipLaunchKernelGGL((k_tiles<(F)>), dim3(((F) & TILE256) ? 64 : 16, npacks), dim3(256), 0, 0, dicts, doffs, ((F) & ZIPF) ? zids : ids, out, npacks, pack_out_stride); })
     RUN(WAVE_TILES, fixed_bytes, "wave owns a 1024-row tile (48-byte rows, row by division, position hashed)");
     RUN(WAVE_TILES | LDS_DLT, fixed_bytes, "+ source position from the LDS table");
     RUN(WAVE_TILES | LDS_DLT | SEARCH, fixed_bytes, "+ 9-step row search in LDS");
-    RUN(WAVE_TILES | LDS_DLT | SEARCH | OCC6, fixed_bytes, "+ 6 waves per SIMD at most, 8 KB of LDS per wave");
+    RUN(WAVE_TILES | LDS_DLT | SEARCH | OCC6, fixed_bytes, "+ 6 waves per SIMD at most (the kernel's launch bound)");
     RUN(WAVE_TILES | LDS_DLT | SEARCH | OCC6 | VARLEN, var_bytes, "+ rows of 20..80 bytes (straddling chunks take their first row's bytes only)");
     RUN(WAVE_TILES | LDS_DLT | SEARCH | OCC6 | VARLEN | STRADDLE, var_bytes, "+ the straddle loop (gathers of the following rows, byte masks)");
     RUN(WAVE_TILES | LDS_DLT | SEARCH | OCC6 | VARLEN | STRADDLE | MANY_DICTS, var_bytes, "+ one 548 KB dictionary per pack, a pack's blocks on one XCD");
@@ -197,5 +260,25 @@ int main() {
     RUN(WAVE_TILES | LDS_DLT | SEARCH | OCC6 | VARLEN | STRADDLE | IDS, var_bytes, "  the same with ONE dictionary for all packs");
     RUN(WAVE_TILES | LDS_DLT | SEARCH | OCC6 | VARLEN | MANY_DICTS | IDS, var_bytes, "  the same without the straddle loop");
     RUN(WAVE_TILES | LDS_DLT | SEARCH | VARLEN | STRADDLE | MANY_DICTS | IDS, var_bytes, "  the same without the occupancy bound");
+    constexpr int FULL = WAVE_TILES | LDS_DLT | SEARCH | OCC6 | VARLEN | STRADDLE | MANY_DICTS | IDS;
+    printf("-- candidate remedies on the full loop (first line: the full loop again)\n");
+    RUN(FULL, var_bytes, "full loop, uniform ids");
+    RUN(FULL | ZIPF, var_bytes, "full loop, Zipf(1.1) ids");
+    RUN((FULL & ~MANY_DICTS) | ZIPF, var_bytes, "  Zipf ids, ONE dictionary for all packs");
+    RUN(FULL | ZIPF | TRIM, var_bytes, "  Zipf ids + the last step of a pass skips idle chunk slots");
+    RUN(FULL | ZIPF | ALIGN128, var_bytes, "  Zipf ids + chunk grid aligned to 128-byte lines");
+    RUN(FULL | ZIPF | TRIM | ALIGN128, var_bytes, "  Zipf ids + both");
+    RUN(FULL | ZIPF | TILE256, var_bytes, "  Zipf ids + a wave owns 256 rows (a quarter of the packs in flight)");
+    RUN(FULL | ZIPF | TILE256 | TRIM | ALIGN128, var_bytes, "  Zipf ids + 256-row tiles + trim + aligned grid");
+    RUN(FULL | ZIPF | PREFV, var_bytes, "  Zipf ids + every workgroup streams 1/16 of the pack's dictionary into L2 first");
+    RUN(FULL | ZIPF | PREFL, var_bytes, "  Zipf ids + the same warm-up with one dword load per 128-byte line");
+    RUN(FULL | PREFV, var_bytes, "  uniform ids + dictionary streamed into L2 first");
+    RUN(FULL | ZIPF | PREFV | TILE256, var_bytes, "  Zipf ids + 256-row tiles + dictionary streamed into L2 first (1/64 per workgroup)");
+    RUN(FULL | ZIPF | NOREMAP, var_bytes, "  Zipf ids, per-pack dictionaries WITHOUT the XCD relabelling");
+    RUN((FULL & ~MANY_DICTS) | ZIPF | REMAP1, var_bytes, "  Zipf ids, ONE dictionary WITH the XCD relabelling");
+    RUN(FULL | ZIPF | ONE_DOFF, var_bytes, "  Zipf ids, per-pack dictionaries, ONE offset table for all packs");
+    RUN((FULL & ~STRADDLE) | ZIPF | PREFV, var_bytes, "  Zipf ids + dictionary streamed first, without the straddle loop");
+    RUN(FULL | TILE256, var_bytes, "  uniform ids + a wave owns 256 rows");
+    RUN(FULL | TILE256 | TRIM | ALIGN128, var_bytes, "  uniform ids + 256-row tiles + trim + aligned grid");
     return 0;
 }
