@@ -2605,8 +2605,12 @@ __global__ __launch_bounds__(256) void k_str_copy(const DevPack* __restrict__ pa
 using FusedWin = WinT<2048>;
 constexpr uint32_t kFusedPassRows = IXR_FUSED_PASS_ROWS;
 constexpr uint32_t kFusedDltOff = (4 * (kFusedPassRows + 1) + 15) & ~15u;  // the deltas start 16-byte aligned behind the offsets
-constexpr uint32_t kFusedWaveLds =                      // per wave: stream window + id tile while expanding, then offsets[] + deltas[]
+#ifndef IXR_FUSED_WAVE_LDS
+#define IXR_FUSED_WAVE_LDS 0    // build switch: pad a wave's LDS to this many bytes (fewer workgroups, so fewer packs in flight, per compute unit)
+#endif
+constexpr uint32_t kFusedWaveNeed =                     // per wave: stream window + id tile while expanding, then offsets[] + deltas[]
     ((FusedWin::kAlloc + 2 * kRleTile > kFusedDltOff + 4 * kFusedPassRows ? FusedWin::kAlloc + 2 * kRleTile : kFusedDltOff + 4 * kFusedPassRows) + 15) & ~15u;
+constexpr uint32_t kFusedWaveLds = kFusedWaveNeed > IXR_FUSED_WAVE_LDS ? kFusedWaveNeed : IXR_FUSED_WAVE_LDS;
 static_assert(kRleTile % kFusedPassRows == 0 && kFusedPassRows % 256 == 0, "a pass is a whole number of 256-row groups");
 
 #ifndef IXR_FUSED_WAVES_PER_SIMD

@@ -40,7 +40,7 @@ template <typename U> __device__ __forceinline__ U wave_incl_scan(U v) {
     return v;
 }
 enum { WAVE_TILES = 1, LDS_DLT = 2, SEARCH = 4, VARLEN = 8, STRADDLE = 16, MANY_DICTS = 32, IDS = 64, OCC6 = 128,
-       ZIPF = 256, TRIM = 512, ALIGN128 = 1024, TILE256 = 2048, PREFV = 4096, NOREMAP = 8192, REMAP1 = 16384, ONE_DOFF = 32768, PREFL = 65536 };
+       ZIPF = 256, TRIM = 512, ALIGN128 = 1024, TILE256 = 2048, PREFV = 4096, NOREMAP = 8192, REMAP1 = 16384, ONE_DOFF = 32768, PREFL = 65536, LDS40 = 131072, LDS80 = 262144 };
 constexpr uint32_t kDictBytes = 548 * 1024, kDictEntries = 11000;
 
 // block-organised baseline: a workgroup writes 64 KB of 48-byte rows, chunk -> row by division, position hashed
@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256, (F & OCC6) ? 6 : 1) void k_tiles(const uint8_t
                                                                   uint32_t npacks, uint32_t pack_out_stride) {
     constexpr uint32_t kTileRows = (F & TILE256) ? 256 : 1024, kPassRows = (F & TILE256) ? 256 : 512;
     constexpr uint32_t kTilesPerPack = 65536 / kTileRows;
-    constexpr uint32_t kWaveLds = 4 * (512 + 4) * 2;  // 4128 bytes per wave, as the string kernel has (offsets and deltas of 512 rows)
+    // 4128 bytes per wave, as the string kernel has (offsets and deltas of 512 rows); LDS40 / LDS80 pad a workgroup to 40 / 80 KB:
+    // 4 / 2 workgroups (16 / 8 waves) per compute unit, so fewer packs in flight per XCD
+    constexpr uint32_t kWaveLds = (F & LDS80) ? 20480 : ((F & LDS40) ? 10240 : 4 * (512 + 4) * 2);
     __shared__ __align__(16) uint8_t smem[4][kWaveLds];
     // grid (16, packs); with MANY_DICTS all blocks of a pack share one XCD (linear ids equal mod 8)
     uint32_t bx = blockIdx.x, by = blockIdx.y;
@@ -272,6 +274,12 @@ int main() {
     RUN(FULL | ZIPF | TILE256 | TRIM | ALIGN128, var_bytes, "  Zipf ids + 256-row tiles + trim + aligned grid");
     RUN(FULL | ZIPF | PREFV, var_bytes, "  Zipf ids + every workgroup streams 1/16 of the pack's dictionary into L2 first");
     RUN(FULL | ZIPF | PREFL, var_bytes, "  Zipf ids + the same warm-up with one dword load per 128-byte line");
+    RUN(FULL | ZIPF | PREFL | TILE256, var_bytes, "  Zipf ids + line warm-up + 256-row tiles");
+    RUN(FULL | PREFL | TILE256, var_bytes, "  uniform ids + line warm-up + 256-row tiles");
+    RUN(FULL | PREFL, var_bytes, "  uniform ids + line warm-up");
+    RUN(FULL | ZIPF | PREFL | LDS40, var_bytes, "  Zipf ids + line warm-up, 16 waves per compute unit (8 packs in flight per XCD)");
+    RUN(FULL | ZIPF | PREFL | LDS80, var_bytes, "  Zipf ids + line warm-up, 8 waves per compute unit (4 packs in flight per XCD)");
+    RUN(FULL | PREFL | LDS40, var_bytes, "  uniform ids + line warm-up, 16 waves per compute unit");
     RUN(FULL | PREFV, var_bytes, "  uniform ids + dictionary streamed into L2 first");
     RUN(FULL | ZIPF | PREFV | TILE256, var_bytes, "  Zipf ids + 256-row tiles + dictionary streamed into L2 first (1/64 per workgroup)");
     RUN(FULL | ZIPF | NOREMAP, var_bytes, "  Zipf ids, per-pack dictionaries WITHOUT the XCD relabelling");
