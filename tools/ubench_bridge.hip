@@ -40,7 +40,7 @@ template <typename U> __device__ __forceinline__ U wave_incl_scan(U v) {
     return v;
 }
 enum { WAVE_TILES = 1, LDS_DLT = 2, SEARCH = 4, VARLEN = 8, STRADDLE = 16, MANY_DICTS = 32, IDS = 64, OCC6 = 128,
-       ZIPF = 256, TRIM = 512, ALIGN128 = 1024, TILE256 = 2048, PREFV = 4096, NOREMAP = 8192, REMAP1 = 16384, ONE_DOFF = 32768, PREFL = 65536, LDS40 = 131072, LDS80 = 262144 };
+       ZIPF = 256, TRIM = 512, ALIGN128 = 1024, TILE256 = 2048, PREFV = 4096, NOREMAP = 8192, REMAP1 = 16384, ONE_DOFF = 32768, PREFL = 65536, LDS40 = 131072, LDS80 = 262144, PREFL64 = 524288 };
 constexpr uint32_t kDictBytes = 548 * 1024, kDictEntries = 11000;
 
 // block-organised baseline: a workgroup writes 64 KB of 48-byte rows, chunk -> row by division, position hashed
@@ -90,6 +90,18 @@ __global__ __launch_bounds__(256, (F & OCC6) ? 6 : 1) void k_tiles(const uint8_t
         }
 #pragma unroll
         for (uint32_t k = 0; k < 9; k++) asm volatile("" ::"v"(v[k].x), "v"(v[k].y), "v"(v[k].z), "v"(v[k].w));  // the data is not used
+    }
+    if (F & PREFL64) {  // one dword per 64 bytes: six loads per lane
+        const uint32_t share = (dict_span / gridDim.x + 127u) & ~127u;
+        const uint8_t* p0 = dict + 64 + (size_t)bx * share;
+        uint32_t v[6];
+#pragma unroll
+        for (uint32_t k = 0; k < 6; k++) {
+            const uint32_t o = (threadIdx.x + k * 256u) * 64u;
+            v[k] = *(const uint32_t*)(p0 + min(o, share - 64u));
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 6; k++) asm volatile("" ::"v"(v[k]));
     }
     if (F & PREFL) {
         const uint32_t share = (dict_span / gridDim.x + 127u) & ~127u;
@@ -274,6 +286,7 @@ int main() {
     RUN(FULL | ZIPF | TILE256 | TRIM | ALIGN128, var_bytes, "  Zipf ids + 256-row tiles + trim + aligned grid");
     RUN(FULL | ZIPF | PREFV, var_bytes, "  Zipf ids + every workgroup streams 1/16 of the pack's dictionary into L2 first");
     RUN(FULL | ZIPF | PREFL, var_bytes, "  Zipf ids + the same warm-up with one dword load per 128-byte line");
+    RUN(FULL | ZIPF | PREFL64, var_bytes, "  Zipf ids + warm-up with one dword load per 64 bytes");
     RUN(FULL | ZIPF | PREFL | TILE256, var_bytes, "  Zipf ids + line warm-up + 256-row tiles");
     RUN(FULL | PREFL | TILE256, var_bytes, "  uniform ids + line warm-up + 256-row tiles");
     RUN(FULL | PREFL, var_bytes, "  uniform ids + line warm-up");
