@@ -64,6 +64,8 @@ def parse_args():
     ap.add_argument("--encode", action="store_true", help="also time the device encoder on the numeric packs of the first chunk (decode, then re-encode); the bytes are compared with the packs the decode started from")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the N > 1 code path on one GPU")
     ap.add_argument("--with-copies", action="store_true", help="also time H2D + decode + D2H from/to pinned host memory on a sample")
+    ap.add_argument("--copy-groups", type=int, default=8, help="groups per plan for the with-copies runs (the pipeline's granularity)")
+    ap.add_argument("--with-copies-full", action="store_true", help="the same for the WHOLE table: slice after slice (1024 pack ids x columns each) through ixr_plan_run_host, pinned host memory in and out")
     return ap.parse_args()
 
 
@@ -206,7 +208,8 @@ def main():
     d_in.upload(np.zeros(L.IN_SLACK, dtype=np.uint8), in_off)
     h2d_s = time.time() - t1
     host_chunks = None
-    table.chunks = None  # the compressed table now lives in HBM; the CPU legs keep the first chunk (table.sample)
+    if not args.with_copies_full:
+        table.chunks = None  # the compressed table now lives in HBM; the CPU legs keep the first chunk (table.sample)
     plan = L.Plan(device, all_descs, int(args.scratch_gib * (1 << 30)))
     log("H2D %.2f GB in %.2f s (pageable); plan: scratch %.2f GB" % (in_bytes / 1e9, h2d_s, plan.scratch_bytes / 1e9))
 
@@ -324,7 +327,11 @@ def main():
     # ------------------------------------------------------------------ optional: rate including the PCIe copies
     with_copies = None
     if args.with_copies and rank == 0:
-        with_copies = time_with_copies(L, np, device, sample_for_cpu, args.scratch_gib)
+        with_copies = time_with_copies(L, np, device, sample_for_cpu, args.scratch_gib, args.copy_groups)
+
+    if args.with_copies_full and rank == 0:
+        full = time_with_copies_full(L, np, device, table, args.scratch_gib, log, args.copy_groups)
+        with_copies = dict(with_copies or {}, whole_table=full)
 
     dict_structs = None
     if args.dict_structs and rank == 0:
@@ -501,7 +508,7 @@ def time_cpu_oracle(np, sample, threads, target_s, log):
             "single_thread": {"value": round(gbs1, 3), "unit": "GB/s", "cores": 1, "sample_packs": m1, "seconds": round(dt1, 2)}}
 
 
-def time_with_copies(L, np, device, sample, scratch_gib):
+def time_with_copies(L, np, device, sample, scratch_gib, groups=8):
     """Compressed packs in pinned host memory -> decoded packs in pinned host memory, on the first chunk of the table:
     ixr_plan_run_host (copy in, decode and copy out of successive groups overlapped on three streams; the plan is built
     with a scratch budget that cuts the chunk into about eight groups) beside the plain sequence H2D, decode, D2H."""
@@ -533,7 +540,7 @@ def time_with_copies(L, np, device, sample, scratch_gib):
     t_plain = best_of(plain)
     _, bad_plain = whole.status()
     d_in.free(); d_out.free()
-    piped = L.Plan(device, descs, max(whole.scratch_bytes // 8, 64 << 20))
+    piped = L.Plan(device, descs, max(whole.scratch_bytes // groups, 64 << 20))
     t_piped = best_of(lambda: piped.run_host(h_in.ptr, in_bytes, h_out.ptr, out_bytes))
     _, bad_piped = piped.status()
     res = {"decoded_GBps": round(whole.total_out / t_piped / 1e9, 2), "rows_per_s": round(whole.total_rows / t_piped, 1), "packs": whole.n,
@@ -545,6 +552,77 @@ def time_with_copies(L, np, device, sample, scratch_gib):
     whole.destroy(); piped.destroy()
     h_in.free(); h_out.free()
     return res
+
+
+def time_with_copies_full(L, np, device, table, scratch_gib, log, groups=8):
+    """The whole table from pinned host memory to pinned host memory: the table's chunks (1024 pack ids of every column) go
+    through ixr_plan_run_host one after the other, each with a plan of its own.  All plans are built before the first timed
+    call and destroyed after the last, as a reader holds the plans of the segments it has open: releasing a plan's device
+    memory slows the copies of the following ~0.7 s down to about half (measured: tools/dbg/run_host_calls.py), so a
+    make-and-destroy loop would time the driver's clean-up, not the pipeline.  A plan's first call, which also allocates
+    its staging buffers, is made untimed; the time is the sum of the second ixr_plan_run_host call of every slice.  Copying
+    a chunk's compressed bytes into the pinned buffer beforehand stands for the reader's read from storage and is not
+    timed.  Every 16th decoded pack of every chunk is checked against the checksum of its source rows."""
+    chunks = sorted(table.chunks, key=lambda c: c[0])
+    bounds = [c[0] for c in chunks] + [table.in_bytes - L.IN_SLACK]
+    descs = sorted(zip(table.descs, table.sums), key=lambda ds: ds[0].in_off)
+    max_in = max(len(c[1]) for c in chunks) + L.IN_SLACK
+    per_chunk, k = [], 0
+    for ci in range(len(chunks)):
+        lo = k
+        while k < len(descs) and descs[k][0].in_off < bounds[ci + 1]:
+            k += 1
+        per_chunk.append(descs[lo:k])
+    max_out = max(max(d.out_off + d.data_size for d, _ in pc) - min(d.out_off for d, _ in pc) for pc in per_chunk if pc) + 32
+    h_in, h_out = L.PinnedBuffer(max_in), L.PinnedBuffer(max_out)
+    total_s, total_out, total_in, total_rows, bad, checked, wrong, packs = 0.0, 0, 0, 0, 0, 0, 0, 0
+    plans = []
+    try:
+        budget = None
+        for ci, pc in enumerate(per_chunk):
+            if not pc:
+                plans.append(None)
+                continue
+            in_lo, out_lo = chunks[ci][0], min(d.out_off for d, _ in pc)
+            local = [L.PackDesc(d.in_off - in_lo, d.out_off - out_lo, d.pack_size, d.data_size, d.obj_count, d.encode_type, d.data_type, 0)
+                     for d, _ in pc]
+            if budget is None:
+                whole = L.Plan(device, local, int(scratch_gib * (1 << 30)))
+                budget = max(whole.scratch_bytes // groups, 64 << 20)  # about `groups` groups per slice: the pipeline's granularity
+                whole.destroy()
+            plans.append((L.Plan(device, local, budget), local))
+        time.sleep(1.5)  # the one plan released above: let the driver finish with its memory
+        for ci, pc in enumerate(per_chunk):
+            if not pc:
+                continue
+            plan, local = plans[ci]
+            body = chunks[ci][1]
+            h_in.array[:len(body)] = body
+            h_in.array[len(body):len(body) + L.IN_SLACK] = 0
+            plan.run_host(h_in.ptr, len(body) + L.IN_SLACK, h_out.ptr, max_out)
+            h_out.array[:4096] = 0
+            L.lib.ixr_dev_synchronize(device)
+            t = time.perf_counter()
+            plan.run_host(h_in.ptr, len(body) + L.IN_SLACK, h_out.ptr, max_out)
+            total_s += time.perf_counter() - t
+            _, b = plan.status()
+            bad += int(b)
+            total_out += plan.total_out; total_in += plan.total_in; total_rows += plan.total_rows; packs += plan.n
+            for (d, want), ld in list(zip(pc, local))[::16]:
+                checked += 1
+                wrong += int(L.checksum(h_out.array[ld.out_off:ld.out_off + ld.data_size]) != int(want))
+            if ci % 4 == 0:
+                log("with copies: chunk %d / %d, %.1f GB/s so far" % (ci + 1, len(per_chunk), total_out / max(total_s, 1e-9) / 1e9))
+    finally:
+        for pl in plans:
+            if pl:
+                pl[0].destroy()
+        h_in.free(); h_out.free()
+    return {"decoded_GBps": round(total_out / total_s / 1e9, 2), "rows_per_s": round(total_rows / total_s, 1), "packs": packs,
+            "compressed_GB": round(total_in / 1e9, 3), "decoded_GB": round(total_out / 1e9, 3), "ms": round(total_s * 1e3, 1),
+            "slices": len([pc for pc in per_chunk if pc]), "groups_per_slice": groups, "bad_packs": bad, "checked_packs": checked,
+            "checksum_mismatches": wrong,
+            "note": "sum of the ixr_plan_run_host calls over all slices of the table; pinned host memory in and out; plans built beforehand"}
 
 
 def time_dict_structs(L, np, device, sample, scratch_gib):
