@@ -20,6 +20,18 @@
 //   REMAP1       one dictionary, but with the XCD relabelling
 //   ONE_DOFF     per-pack dictionaries, one offset table for all packs
 //   PREFL        the same warm-up with ONE dword load per 128-byte line (two or three loads per lane instead of nine of 16 bytes)
+//   PREFW        line warm-up of FOUR shares per workgroup (its own and the three that follow): with 64 small workgroups per pack
+//                a share is 1/64 of the dictionary, and the first workgroups of a pack gather before the others have arrived
+//   PREFS        the same with the four shares spread over the dictionary (own, +1/4, +2/4, +3/4): a quarter of the pack's
+//                workgroups warms all of it
+//   PREFA1/2/3   a workgroup warms its share (1/64) of the dictionary of the pack its XCD takes one, two or three packs LATER:
+//                with 256-row tiles only three packs are in flight per XCD, so the L2 has room for the dictionaries to come
+//   PREFK        line warm-up through SCALAR loads (one dword per line, a wave takes a quarter of the workgroup's share): they
+//                fill L2 on their way like any load, but return through the scalar cache, not through the vector L1's
+//                in-order queue, so a miss among them holds back nobody's gathers.  PREFK4: four spread shares as PREFS
+//   PREFST       instead of warming by loads, a workgroup STORES its share of the pack's dictionary (the same bytes it holds):
+//                what a producer that writes the dictionary just before its use would do; stores return nothing
+//   FEWDICTS     per-pack addressing, but only four dictionaries in all (pack & 3): always in L2 after the first touches
 //   PREFV        before its tiles, a workgroup streams its share (1/16) of the pack's dictionary through coalesced 16-byte loads
 //                whose data it throws away: the gathers that follow find the lines in the XCD's L2
 #include <hip/hip_runtime.h>
@@ -40,7 +52,7 @@ template <typename U> __device__ __forceinline__ U wave_incl_scan(U v) {
     return v;
 }
 enum { WAVE_TILES = 1, LDS_DLT = 2, SEARCH = 4, VARLEN = 8, STRADDLE = 16, MANY_DICTS = 32, IDS = 64, OCC6 = 128,
-       ZIPF = 256, TRIM = 512, ALIGN128 = 1024, TILE256 = 2048, PREFV = 4096, NOREMAP = 8192, REMAP1 = 16384, ONE_DOFF = 32768, PREFL = 65536, LDS40 = 131072, LDS80 = 262144, PREFL64 = 524288 };
+       ZIPF = 256, TRIM = 512, ALIGN128 = 1024, TILE256 = 2048, PREFV = 4096, NOREMAP = 8192, REMAP1 = 16384, ONE_DOFF = 32768, PREFL = 65536, LDS40 = 131072, LDS80 = 262144, PREFL64 = 524288, PREFW = 1 << 20, PREFS = 1 << 21, PREFA2 = 1 << 22, PREFA3 = 1 << 23, PREFA1 = 1 << 24, PREFK = 1 << 25, PREFK4 = 1 << 26, PREFST = 1 << 27, FEWDICTS = 1 << 28 };
 constexpr uint32_t kDictBytes = 548 * 1024, kDictEntries = 11000;
 
 // block-organised baseline: a workgroup writes 64 KB of 48-byte rows, chunk -> row by division, position hashed
@@ -59,27 +71,20 @@ __global__ __launch_bounds__(256) void k_block(const uint8_t* __restrict__ dict,
 }
 
 template <int F>
-__global__ __launch_bounds__(256, (F & OCC6) ? 6 : 1) void k_tiles(const uint8_t* __restrict__ dicts, const uint32_t* __restrict__ doffs,
-                                                                  const uint16_t* __restrict__ ids, uint8_t* __restrict__ out,
-                                                                  uint32_t npacks, uint32_t pack_out_stride) {
+__device__ __forceinline__ void tiles_body(uint32_t bx, uint32_t by, const uint32_t gx, const uint8_t* __restrict__ dicts, const uint32_t* __restrict__ doffs,
+                                           const uint16_t* __restrict__ ids, uint8_t* __restrict__ out, uint32_t npacks, uint32_t pack_out_stride) {
     constexpr uint32_t kTileRows = (F & TILE256) ? 256 : 1024, kPassRows = (F & TILE256) ? 256 : 512;
     constexpr uint32_t kTilesPerPack = 65536 / kTileRows;
     // 4128 bytes per wave, as the string kernel has (offsets and deltas of 512 rows); LDS40 / LDS80 pad a workgroup to 40 / 80 KB:
     // 4 / 2 workgroups (16 / 8 waves) per compute unit, so fewer packs in flight per XCD
     constexpr uint32_t kWaveLds = (F & LDS80) ? 20480 : ((F & LDS40) ? 10240 : 4 * (512 + 4) * 2);
     __shared__ __align__(16) uint8_t smem[4][kWaveLds];
-    // grid (16, packs); with MANY_DICTS all blocks of a pack share one XCD (linear ids equal mod 8)
-    uint32_t bx = blockIdx.x, by = blockIdx.y;
-    if (((F & MANY_DICTS) && !(F & NOREMAP)) || (F & REMAP1)) {
-        const uint32_t gx = gridDim.x, L = blockIdx.y * gx + blockIdx.x, full = npacks & ~7u;
-        if (L < full * gx) { const uint32_t xcd = L & 7u, sidx = L >> 3; by = (sidx / gx) * 8u + ((xcd + sidx / gx) & 7u); bx = sidx % gx; }
-    }
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tile = bx * 4 + wave, pack = by;
-    const uint8_t* dict = (F & MANY_DICTS) ? dicts + (size_t)pack * (kDictBytes + 256) : dicts;
+    const uint8_t* dict = (F & MANY_DICTS) ? dicts + (size_t)((F & FEWDICTS) ? (pack & 3u) : pack) * (kDictBytes + 256) : dicts;
     const uint32_t dict_span = (F & MANY_DICTS) ? kDictBytes : (1u << 20);
     const uint32_t* doff = doffs + (((F & MANY_DICTS) && !(F & ONE_DOFF)) ? (size_t)pack * (kDictEntries + 8) : 0);
     if (F & PREFV) {
-        const uint32_t share = dict_span / gridDim.x & ~15u;  // bytes of the dictionary this workgroup warms up
+        const uint32_t share = dict_span / gx & ~15u;  // bytes of the dictionary this workgroup warms up
         const uint8_t* p0 = dict + 64 + (size_t)bx * share;
         // all loads are issued before any is waited for (nine cover a sixteenth of 548 KB at 256 lanes x 16 bytes)
         uint4 v[9];
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(256, (F & OCC6) ? 6 : 1) void k_tiles(const uint8_t
         for (uint32_t k = 0; k < 9; k++) asm volatile("" ::"v"(v[k].x), "v"(v[k].y), "v"(v[k].z), "v"(v[k].w));  // the data is not used
     }
     if (F & PREFL64) {  // one dword per 64 bytes: six loads per lane
-        const uint32_t share = (dict_span / gridDim.x + 127u) & ~127u;
+        const uint32_t share = (dict_span / gx + 127u) & ~127u;
         const uint8_t* p0 = dict + 64 + (size_t)bx * share;
         uint32_t v[6];
 #pragma unroll
@@ -104,13 +109,74 @@ __global__ __launch_bounds__(256, (F & OCC6) ? 6 : 1) void k_tiles(const uint8_t
         for (uint32_t k = 0; k < 6; k++) asm volatile("" ::"v"(v[k]));
     }
     if (F & PREFL) {
-        const uint32_t share = (dict_span / gridDim.x + 127u) & ~127u;
+        const uint32_t share = (dict_span / gx + 127u) & ~127u;
         const uint8_t* p0 = dict + 64 + (size_t)bx * share;
         uint32_t v[3];
 #pragma unroll
         for (uint32_t k = 0; k < 3; k++) {
             const uint32_t o = (threadIdx.x + k * 256u) * 128u;
             v[k] = *(const uint32_t*)(p0 + min(o, share - 128u));
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 3; k++) asm volatile("" ::"v"(v[k]));
+    }
+    if (F & (PREFA1 | PREFA2 | PREFA3)) {
+        // the pack this XCD takes D packs from now (the relabelling above, inverted): none for the last D groups of eight
+        const uint32_t D = (F & PREFA1) ? 1u : ((F & PREFA2) ? 2u : 3u);
+        const uint32_t Lb = blockIdx.y * gx + blockIdx.x, full = npacks & ~7u;
+        if (Lb < full * gx) {
+            const uint32_t xcd = Lb & 7u, grp = (Lb >> 3) / gx + D;
+            if (grp * 8u + 8u <= full) {
+                const uint32_t ahead = grp * 8u + ((xcd + grp) & 7u);  // < full <= npacks
+                const uint8_t* ad = dicts + (size_t)ahead * (kDictBytes + 256);
+                const uint32_t lines = (dict_span + 127u) >> 7, per = (lines + gx - 1u) / gx;
+                uint32_t v[2];
+#pragma unroll
+                for (uint32_t k = 0; k < 2; k++) {
+                    const uint32_t idx = threadIdx.x + k * 256u, line = bx * per + idx;
+                    v[k] = *(const uint32_t*)(ad + 64 + 128ull * ((idx < per && line < lines) ? line : 0u));
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 2; k++) asm volatile("" ::"v"(v[k]));
+            }
+        }
+    }
+    if (F & PREFST) {
+        const uint32_t lines = (dict_span + 127u) >> 7, per = (lines + gx - 1u) / gx;
+        uint8_t* wd = const_cast<uint8_t*>(dict) + 64 + (size_t)bx * per * 128u;
+#pragma unroll
+        for (uint32_t k = 0; k < 3; k++) {
+            const uint32_t idx = threadIdx.x + k * 256u;  // 16-byte piece of the share
+            if (idx < per * 8u && bx * per * 128u + idx * 16u + 16u <= dict_span) *(uint4*)(wd + idx * 16u) = make_uint4(0x07070707u, 0x07070707u, 0x07070707u, 0x07070707u);
+        }
+    }
+    uint32_t kv[18];
+    if (F & (PREFK | PREFK4)) {
+        typedef const uint32_t __attribute__((address_space(4))) * kp;
+        const uint32_t lines = (dict_span + 127u) >> 7, per = (lines + gx - 1u) / gx, perw = (per + 3u) / 4u;
+        const uint32_t wv = __builtin_amdgcn_readfirstlane(wave), bxu = __builtin_amdgcn_readfirstlane(bx);
+        // PREFK: wave w takes lines [w * perw, (w + 1) * perw) of the workgroup's share; PREFK4: wave w takes the WHOLE share of
+        // workgroup bx + w * gx / 4 (the four spread shares, one per wave)
+        const uint32_t share = (F & PREFK4) ? (bxu + wv * (gx / 4u)) % gx : bxu;
+        const uint32_t first = (F & PREFK4) ? 0u : wv * perw, count = (F & PREFK4) ? per : perw;
+#pragma unroll
+        for (uint32_t k = 0; k < 18; k++) {
+            const uint32_t within = first + k, line = share * per + within;
+            const bool ok = k < count && within < per && line < lines;
+            const uint64_t a = (uint64_t)(dict + 64 + 128ull * (ok ? line : 0u));
+            const uint64_t au = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a);
+            kv[k] = *(kp)au;
+        }
+    }
+    if (F & (PREFW | PREFS)) {
+        const uint32_t lines = (dict_span + 127u) >> 7, per = (lines + gx - 1u) / gx;  // lines per share
+        uint32_t v[3];
+#pragma unroll
+        for (uint32_t k = 0; k < 3; k++) {
+            const uint32_t idx = threadIdx.x + k * 256u, s = idx / per, within = idx - s * per;
+            const uint32_t share = ((F & PREFS) ? bx + s * (gx / 4u) : bx + s) % gx;
+            const uint32_t line = share * per + within;
+            v[k] = *(const uint32_t*)(dict + 64 + 128ull * ((s < 4u && line < lines) ? line : 0u));  // line < lines: inside the dictionary
         }
 #pragma unroll
         for (uint32_t k = 0; k < 3; k++) asm volatile("" ::"v"(v[k]));
@@ -213,6 +279,67 @@ __global__ __launch_bounds__(256, (F & OCC6) ? 6 : 1) void k_tiles(const uint8_t
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
     }
+    if (F & (PREFK | PREFK4)) {
+#pragma unroll
+        for (uint32_t k = 0; k < 18; k++) asm volatile("" ::"s"(kv[k]));
+    }
+}
+
+
+template <int F>
+__global__ __launch_bounds__(256, (F & OCC6) ? 6 : 1) void k_tiles(const uint8_t* __restrict__ dicts, const uint32_t* __restrict__ doffs,
+                                                                  const uint16_t* __restrict__ ids, uint8_t* __restrict__ out,
+                                                                  uint32_t npacks, uint32_t pack_out_stride) {
+    // grid (16 or 64, packs); with MANY_DICTS all blocks of a pack share one XCD (linear ids equal mod 8)
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    if (((F & MANY_DICTS) && !(F & NOREMAP)) || (F & REMAP1)) {
+        const uint32_t gx = gridDim.x, L = blockIdx.y * gx + blockIdx.x, full = npacks & ~7u;
+        if (L < full * gx) { const uint32_t xcd = L & 7u, sidx = L >> 3; by = (sidx / gx) * 8u + ((xcd + sidx / gx) & 7u); bx = sidx % gx; }
+    }
+    tiles_body<F>(bx, by, gridDim.x, dicts, doffs, ids, out, npacks, pack_out_stride);
+}
+
+// Producer / consumer pipeline in ONE launch: per XCD the blocks come in steps of 16 + 64; the first 16 of step k WRITE the
+// dictionary of the XCD's k-th pack (a sixteenth each, the bytes it already holds), publish with a device-scope counter, and
+// exit; the other 64 are the 256-row-tile workgroups of the pack of step k - LAG, which wait for that pack's counter to reach
+// 16 before they gather.  Workgroups are dispatched in the order of their linear ids, a consumer only waits for producers
+// with smaller ids, and producers wait for nothing: the wait ends.  It is bounded all the same (err is set, the tile skipped).
+template <int F, int LAG>
+__global__ __launch_bounds__(256, 6) void k_pipe(const uint8_t* __restrict__ dicts, const uint32_t* __restrict__ doffs,
+                                                 const uint16_t* __restrict__ ids, uint8_t* __restrict__ out, uint32_t npacks,
+                                                 uint32_t pack_out_stride, uint32_t* __restrict__ flags, uint32_t* __restrict__ err) {
+    const uint32_t L = blockIdx.x, xcd = L & 7u, s = L >> 3, k = s / 80u, j = s % 80u, npx = npacks >> 3;  // npacks is a multiple of 8
+    if (j < 16u) {
+        if (k >= npx) return;
+        const uint32_t pack = k * 8u + ((xcd + k) & 7u);
+        uint8_t* d = const_cast<uint8_t*>(dicts) + (size_t)pack * (kDictBytes + 256) + 64;
+        const uint32_t share = (kDictBytes / 16u + 15u) & ~15u;  // bytes per producer, a multiple of 16
+#pragma unroll
+        for (uint32_t i = 0; i < 9; i++) {
+            const uint32_t o = j * share + (threadIdx.x + i * 256u) * 16u;
+            if ((threadIdx.x + i * 256u) * 16u < share && o + 16u <= kDictBytes) *(uint4*)(d + o) = make_uint4(0x07070707u, 0x07070707u, 0x07070707u, 0x07070707u);
+        }
+        // Producers and consumers of a pack run on the same XCD, whose L2 is where the stores land (the vector L1 writes through)
+        // and where the counter lives: waiting for the stores' acknowledgements orders them before the count.  A device-scope
+        // release would write the XCD's whole L2 back (measured: the pipeline then takes 4.2 ms).
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(flags + pack, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (k < (uint32_t)LAG || k - LAG >= npx) return;
+    const uint32_t kk = k - LAG, pack = kk * 8u + ((xcd + kk) & 7u);
+    __shared__ uint32_t ready;
+    if (threadIdx.x == 0) {
+        uint32_t spins = 0, v;
+        while ((v = __hip_atomic_load(flags + pack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 16u && ++spins < (1u << 18)) __builtin_amdgcn_s_sleep(8);
+        ready = v >= 16u;
+        if (v < 16u) atomicAdd(err, 1u);
+    }
+    __syncthreads();
+    if (!ready) return;
+    tiles_body<F>(j - 16u, pack, 64u, dicts, doffs, ids, out, npacks, pack_out_stride);
 }
 
 int main() {
@@ -260,6 +387,7 @@ int main() {
         printf("%-86s %8.3f ms  %8.1f GB/s of rows\n", name, best, bytes / 1e9 / (best / 1e3));
     };
     const double fixed_bytes = (double)nrows * 48, var_bytes = (double)nrows * 50;
+    uint32_t* flags; CK(hipMalloc(&flags, (npacks + 1) * 4)); CK(hipMemset(flags, 0, (npacks + 1) * 4));
     timeit("workgroup owns 64 KB: 48-byte rows, position hashed, one 1 MB dictionary", 65536.0 * 50000,
            [&] { hipLaunchKernelGGL(k_block, dim3(50000), dim3(256), 0, 0, dicts, out, 1u << 20); });
 #define RUN(F, bytes, name) timeit(name, bytes, [&] { hipLaunchKernelGGL((k_tiles<(F)>), dim3(((F) & TILE256) ? 64 : 16, npacks), dim3(256), 0, 0, dicts, doffs, ((F) & ZIPF) ? zids : ids, out, npacks, pack_out_stride); })
@@ -289,6 +417,29 @@ int main() {
     RUN(FULL | ZIPF | PREFL64, var_bytes, "  Zipf ids + warm-up with one dword load per 64 bytes");
     RUN(FULL | ZIPF | PREFL | TILE256, var_bytes, "  Zipf ids + line warm-up + 256-row tiles");
     RUN(FULL | PREFL | TILE256, var_bytes, "  uniform ids + line warm-up + 256-row tiles");
+    RUN(FULL | ZIPF | PREFA1 | TILE256 | TRIM | ALIGN128, var_bytes, "  Zipf ids + 256-row tiles + trim + aligned + dictionary of the NEXT pack of the XCD warmed");
+    RUN(FULL | ZIPF | PREFA2 | TILE256 | TRIM | ALIGN128, var_bytes, "  Zipf ids + 256-row tiles + trim + aligned + dictionary two packs ahead warmed");
+    RUN(FULL | ZIPF | PREFA3 | TILE256 | TRIM | ALIGN128, var_bytes, "  Zipf ids + 256-row tiles + trim + aligned + dictionary three packs ahead warmed");
+    RUN(FULL | PREFA2 | TILE256 | TRIM | ALIGN128, var_bytes, "  uniform ids + 256-row tiles + trim + aligned + dictionary two packs ahead warmed");
+    RUN(FULL | ZIPF | PREFA2 | PREFS | TILE256 | TRIM | ALIGN128, var_bytes, "  Zipf ids + 256-row tiles + trim + aligned + two ahead AND own (four spread shares)");
+    RUN(FULL | ZIPF | PREFA1, var_bytes, "  Zipf ids, 1024-row tiles + dictionary of the next pack warmed");
+    RUN(FULL | ZIPF | PREFK | TILE256 | TRIM | ALIGN128, var_bytes, "  Zipf ids + 256-row tiles + trim + aligned + SCALAR-load warm-up of the own share");
+    RUN(FULL | PREFK | TILE256 | TRIM | ALIGN128, var_bytes, "  uniform ids + 256-row tiles + trim + aligned + scalar-load warm-up of the own share");
+    RUN(FULL | ZIPF | PREFK4 | TILE256 | TRIM | ALIGN128, var_bytes, "  Zipf ids + 256-row tiles + trim + aligned + scalar-load warm-up, 18 lines of four spread shares");
+    RUN(FULL | ZIPF | PREFST | TILE256 | TRIM | ALIGN128, var_bytes, "  Zipf ids + 256-row tiles + trim + aligned + the share of the dictionary STORED first");
+    RUN(FULL | PREFST | TILE256 | TRIM | ALIGN128, var_bytes, "  uniform ids + 256-row tiles + trim + aligned + the share of the dictionary stored first");
+    RUN(FULL | ZIPF | FEWDICTS | TILE256 | TRIM | ALIGN128, var_bytes, "  Zipf ids + 256-row tiles + trim + aligned, FOUR dictionaries in all (per-pack addressing)");
+    RUN(FULL | ZIPF | FEWDICTS, var_bytes, "  Zipf ids, 1024-row tiles, four dictionaries in all");
+#define RUNP(F, LAG, name) timeit(name, var_bytes, [&] { (void)hipMemsetAsync(flags, 0, npacks * 4, 0); hipLaunchKernelGGL((k_pipe<(F), LAG>), dim3(8u * (npacks / 8u + LAG) * 80u), dim3(256), 0, 0, dicts, doffs, zids, out, npacks, pack_out_stride, flags, flags + npacks); })
+    RUNP(FULL | ZIPF | TILE256 | TRIM | ALIGN128, 1, "  PIPELINE: 16 producers store a pack's dictionary, its 64 tile workgroups follow one pack later");
+    RUNP(FULL | ZIPF | TILE256 | TRIM | ALIGN128, 2, "  pipeline, consumers two packs behind");
+    RUNP(FULL | ZIPF | TILE256 | TRIM | ALIGN128, 3, "  pipeline, consumers three packs behind");
+    RUNP(FULL | ZIPF | TILE256 | TRIM | ALIGN128, 0, "  pipeline, consumers of the same pack right behind its producers");
+    { uint32_t e = 0; CK(hipMemcpy(&e, flags + npacks, 4, hipMemcpyDeviceToHost)); printf("  pipeline: %u workgroups gave up waiting\n", e); }
+    RUN(FULL | ZIPF | PREFW | TILE256, var_bytes, "  Zipf ids + 256-row tiles + warm-up of four consecutive shares per workgroup");
+    RUN(FULL | ZIPF | PREFS | TILE256, var_bytes, "  Zipf ids + 256-row tiles + warm-up of four spread shares per workgroup");
+    RUN(FULL | PREFS | TILE256, var_bytes, "  uniform ids + 256-row tiles + warm-up of four spread shares");
+    RUN(FULL | ZIPF | PREFS | TILE256 | TRIM | ALIGN128, var_bytes, "  Zipf ids + 256-row tiles + four spread shares + trim + aligned grid");
     RUN(FULL | PREFL, var_bytes, "  uniform ids + line warm-up");
     RUN(FULL | ZIPF | PREFL | LDS40, var_bytes, "  Zipf ids + line warm-up, 16 waves per compute unit (8 packs in flight per XCD)");
     RUN(FULL | ZIPF | PREFL | LDS80, var_bytes, "  Zipf ids + line warm-up, 8 waves per compute unit (4 packs in flight per XCD)");
