@@ -170,16 +170,17 @@ __device__ __forceinline__ void tiles_body(uint32_t bx, uint32_t by, const uint3
     }
     if (F & (PREFW | PREFS)) {
         const uint32_t lines = (dict_span + 127u) >> 7, per = (lines + gx - 1u) / gx;  // lines per share
-        uint32_t v[3];
+        constexpr uint32_t NL = (F & TILE256) ? 3 : 5;  // 64 workgroups: 4 shares = 276 lines; 16 workgroups: 4 shares = 1096 lines
+        uint32_t v[NL];
 #pragma unroll
-        for (uint32_t k = 0; k < 3; k++) {
+        for (uint32_t k = 0; k < NL; k++) {
             const uint32_t idx = threadIdx.x + k * 256u, s = idx / per, within = idx - s * per;
             const uint32_t share = ((F & PREFS) ? bx + s * (gx / 4u) : bx + s) % gx;
             const uint32_t line = share * per + within;
             v[k] = *(const uint32_t*)(dict + 64 + 128ull * ((s < 4u && line < lines) ? line : 0u));  // line < lines: inside the dictionary
         }
 #pragma unroll
-        for (uint32_t k = 0; k < 3; k++) asm volatile("" ::"v"(v[k]));
+        for (uint32_t k = 0; k < NL; k++) asm volatile("" ::"v"(v[k]));
     }
     uint32_t* s_off = (uint32_t*)smem[wave];
     uint32_t* s_dlt = s_off + kPassRows + 4;
@@ -436,6 +437,10 @@ int main() {
     RUNP(FULL | ZIPF | TILE256 | TRIM | ALIGN128, 3, "  pipeline, consumers three packs behind");
     RUNP(FULL | ZIPF | TILE256 | TRIM | ALIGN128, 0, "  pipeline, consumers of the same pack right behind its producers");
     { uint32_t e = 0; CK(hipMemcpy(&e, flags + npacks, 4, hipMemcpyDeviceToHost)); printf("  pipeline: %u workgroups gave up waiting\n", e); }
+    RUN(FULL | ZIPF | PREFS, var_bytes, "  Zipf ids, 1024-row tiles + warm-up of four spread shares (a quarter of the dictionary per workgroup)");
+    RUN(FULL | ZIPF | PREFW, var_bytes, "  Zipf ids, 1024-row tiles + warm-up of four consecutive shares");
+    RUN(FULL | ZIPF | PREFS | TRIM | ALIGN128, var_bytes, "  Zipf ids, 1024-row tiles + four spread shares + trim + aligned grid");
+    RUN(FULL | ZIPF | PREFL | TRIM | ALIGN128, var_bytes, "  Zipf ids, 1024-row tiles + line warm-up + trim + aligned grid");
     RUN(FULL | ZIPF | PREFW | TILE256, var_bytes, "  Zipf ids + 256-row tiles + warm-up of four consecutive shares per workgroup");
     RUN(FULL | ZIPF | PREFS | TILE256, var_bytes, "  Zipf ids + 256-row tiles + warm-up of four spread shares per workgroup");
     RUN(FULL | PREFS | TILE256, var_bytes, "  uniform ids + 256-row tiles + warm-up of four spread shares");
