@@ -32,6 +32,10 @@
 //   PREFST       instead of warming by loads, a workgroup STORES its share of the pack's dictionary (the same bytes it holds):
 //                what a producer that writes the dictionary just before its use would do; stores return nothing
 //   FEWDICTS     per-pack addressing, but only four dictionaries in all (pack & 3): always in L2 after the first touches
+//   COLDWARM     with FEWDICTS and PREFL: the warm-up loads read the PER-PACK dictionary (cold lines from HBM, as the kernel's do)
+//                while the gathers use the four resident dictionaries: the price of the cold loads alone
+//   LATE         with PREFL: nothing waits for the warm-up loads on their own; their registers are only "used" at the end of the
+//                kernel, so the first wait of a wave (for its ids) covers both: one trip to cold memory per wave instead of two
 //   PREFV        before its tiles, a workgroup streams its share (1/16) of the pack's dictionary through coalesced 16-byte loads
 //                whose data it throws away: the gathers that follow find the lines in the XCD's L2
 #include <hip/hip_runtime.h>
@@ -52,8 +56,10 @@ template <typename U> __device__ __forceinline__ U wave_incl_scan(U v) {
     return v;
 }
 enum { WAVE_TILES = 1, LDS_DLT = 2, SEARCH = 4, VARLEN = 8, STRADDLE = 16, MANY_DICTS = 32, IDS = 64, OCC6 = 128,
-       ZIPF = 256, TRIM = 512, ALIGN128 = 1024, TILE256 = 2048, PREFV = 4096, NOREMAP = 8192, REMAP1 = 16384, ONE_DOFF = 32768, PREFL = 65536, LDS40 = 131072, LDS80 = 262144, PREFL64 = 524288, PREFW = 1 << 20, PREFS = 1 << 21, PREFA2 = 1 << 22, PREFA3 = 1 << 23, PREFA1 = 1 << 24, PREFK = 1 << 25, PREFK4 = 1 << 26, PREFST = 1 << 27, FEWDICTS = 1 << 28 };
+       ZIPF = 256, TRIM = 512, ALIGN128 = 1024, TILE256 = 2048, PREFV = 4096, NOREMAP = 8192, REMAP1 = 16384, ONE_DOFF = 32768, PREFL = 65536, LDS40 = 131072, LDS80 = 262144, PREFL64 = 524288, PREFW = 1 << 20, PREFS = 1 << 21, PREFA2 = 1 << 22, PREFA3 = 1 << 23, PREFA1 = 1 << 24, PREFK = 1 << 25, PREFK4 = 1 << 26, PREFST = 1 << 27, FEWDICTS = 1 << 28, COLDWARM = 1 << 29, LATE = 1 << 30 };
 constexpr uint32_t kDictBytes = 548 * 1024, kDictEntries = 11000;
+__device__ uint32_t g_cold_spread = 0;  // COLDWARM with a region: the region's lines lie this many times 128 bytes apart (the same number of lines over a wider address span)
+__device__ uint32_t g_cold_region = 0;  // COLDWARM: wrap the cold warm-up addresses into this many bytes (0 = the per-pack dictionaries as they lie)
 
 // block-organised baseline: a workgroup writes 64 KB of 48-byte rows, chunk -> row by division, position hashed
 __global__ __launch_bounds__(256) void k_block(const uint8_t* __restrict__ dict, uint8_t* __restrict__ out, uint32_t dict_bytes) {
@@ -108,17 +114,31 @@ __device__ __forceinline__ void tiles_body(uint32_t bx, uint32_t by, const uint3
 #pragma unroll
         for (uint32_t k = 0; k < 6; k++) asm volatile("" ::"v"(v[k]));
     }
+    uint32_t lv[3] = {0, 0, 0};
     if (F & PREFL) {
         const uint32_t share = (dict_span / gx + 127u) & ~127u;
         const uint8_t* p0 = dict + 64 + (size_t)bx * share;
-        uint32_t v[3];
+        if (F & COLDWARM) {
+            size_t o = (size_t)pack * (kDictBytes + 256) + (size_t)bx * share;
+            const uint32_t region = g_cold_region;
+            if (region) o = (o % region) & ~(size_t)127;  // the share (<= 35 KB) stays inside the allocation: region <= 512 MB, 2 MB spare at its end
+            p0 = dicts + 64 + o;
+        }
+        const uint32_t spread = (F & COLDWARM) ? g_cold_spread : 0u;
 #pragma unroll
         for (uint32_t k = 0; k < 3; k++) {
             const uint32_t o = (threadIdx.x + k * 256u) * 128u;
-            v[k] = *(const uint32_t*)(p0 + min(o, share - 128u));
+            if (spread) {  // line number within the region, times the spread: region * spread <= 512 MB
+                const size_t line = ((size_t)(p0 - (dicts + 64)) + min(o, share - 128u)) >> 7;
+                lv[k] = *(const uint32_t*)(dicts + 64 + line * 128u * spread);
+            } else {
+                lv[k] = *(const uint32_t*)(p0 + min(o, share - 128u));
+            }
         }
+        if (!(F & LATE)) {
 #pragma unroll
-        for (uint32_t k = 0; k < 3; k++) asm volatile("" ::"v"(v[k]));
+            for (uint32_t k = 0; k < 3; k++) asm volatile("" ::"v"(lv[k]));
+        }
     }
     if (F & (PREFA1 | PREFA2 | PREFA3)) {
         // the pack this XCD takes D packs from now (the relabelling above, inverted): none for the last D groups of eight
@@ -284,6 +304,10 @@ __device__ __forceinline__ void tiles_body(uint32_t bx, uint32_t by, const uint3
 #pragma unroll
         for (uint32_t k = 0; k < 18; k++) asm volatile("" ::"s"(kv[k]));
     }
+    if ((F & PREFL) && (F & LATE)) {
+#pragma unroll
+        for (uint32_t k = 0; k < 3; k++) asm volatile("" ::"v"(lv[k]));
+    }
 }
 
 
@@ -300,11 +324,79 @@ __global__ __launch_bounds__(256, (F & OCC6) ? 6 : 1) void k_tiles(const uint8_t
     tiles_body<F>(bx, by, gridDim.x, dicts, doffs, ids, out, npacks, pack_out_stride);
 }
 
+// Sub-batches: the same tile kernel over packs [pack0, pack0 + gridDim.y), preceded by a kernel that writes (k_fill) or reads
+// (k_touch) those packs' dictionaries: does a dictionary that a kernel has just written or read -- tens of megabytes ago, not
+// gigabytes -- come out of the memory-side cache when the tile kernel asks for it?
+template <int F>
+__global__ __launch_bounds__(256, (F & OCC6) ? 6 : 1) void k_tiles_sub(const uint8_t* __restrict__ dicts, const uint32_t* __restrict__ doffs,
+                                                                      const uint16_t* __restrict__ ids, uint8_t* __restrict__ out,
+                                                                      uint32_t npacks, uint32_t pack_out_stride, uint32_t pack0) {
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    const uint32_t gx = gridDim.x, L = blockIdx.y * gx + blockIdx.x, full = gridDim.y & ~7u;
+    if (L < full * gx) { const uint32_t xcd = L & 7u, sidx = L >> 3; by = (sidx / gx) * 8u + ((xcd + sidx / gx) & 7u); bx = sidx % gx; }
+    if (pack0 + by >= npacks) return;
+    tiles_body<F>(bx, pack0 + by, gridDim.x, dicts, doffs, ids, out, npacks, pack_out_stride);
+}
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_fill_or_touch(uint8_t* __restrict__ dicts, uint32_t npacks, uint32_t pack0) {
+    const uint32_t pack = pack0 + blockIdx.y, j = blockIdx.x;  // grid (16, packs of the sub-batch)
+    if (pack >= npacks) return;
+    uint8_t* d = dicts + (size_t)pack * (kDictBytes + 256) + 64;
+    if (WRITE) {
+        const uint32_t share = (kDictBytes / 16u + 15u) & ~15u;
+#pragma unroll
+        for (uint32_t i = 0; i < 9; i++) {
+            const uint32_t o = j * share + (threadIdx.x + i * 256u) * 16u;
+            if ((threadIdx.x + i * 256u) * 16u < share && o + 16u <= kDictBytes) *(uint4*)(d + o) = make_uint4(0x07070707u, 0x07070707u, 0x07070707u, 0x07070707u);
+        }
+    } else {
+        const uint32_t lines = (kDictBytes + 127u) >> 7, per = (lines + 15u) / 16u;
+        uint32_t v[2];
+#pragma unroll
+        for (uint32_t i = 0; i < 2; i++) {
+            const uint32_t idx = threadIdx.x + i * 256u, line = j * per + idx;
+            v[i] = *(const uint32_t*)(d + 128ull * ((idx < per && line < lines) ? line : 0u));
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < 2; i++) asm volatile("" ::"v"(v[i]));
+    }
+}
+
 // Producer / consumer pipeline in ONE launch: per XCD the blocks come in steps of 16 + 64; the first 16 of step k WRITE the
 // dictionary of the XCD's k-th pack (a sixteenth each, the bytes it already holds), publish with a device-scope counter, and
 // exit; the other 64 are the 256-row-tile workgroups of the pack of step k - LAG, which wait for that pack's counter to reach
 // 16 before they gather.  Workgroups are dispatched in the order of their linear ids, a consumer only waits for producers
 // with smaller ids, and producers wait for nothing: the wait ends.  It is bounded all the same (err is set, the tile skipped).
+// The same launch shape with WARMERS instead of producers: the first 16 workgroups of step k only READ the dictionary of the
+// XCD's k-th pack (one dword per line, a sixteenth each) and exit; nobody waits for anybody (it is a prefetch, not a dependency).
+// The cold reads are then paid by workgroups that have nothing else to do, LAG packs ahead of the ones that gather.
+template <int F, int LAG, int NW>
+__global__ __launch_bounds__(256, 6) void k_warmers(const uint8_t* __restrict__ dicts, const uint32_t* __restrict__ doffs,
+                                                    const uint16_t* __restrict__ ids, uint8_t* __restrict__ out, uint32_t npacks,
+                                                    uint32_t pack_out_stride) {
+    constexpr uint32_t kStep = NW + 64;
+    const uint32_t L = blockIdx.x, xcd = L & 7u, s = L >> 3, k = s / kStep, j = s % kStep, npx = npacks >> 3;  // npacks is a multiple of 8
+    if (j < (uint32_t)NW) {
+        if (k >= npx) return;
+        const uint32_t pack = k * 8u + ((xcd + k) & 7u);
+        const uint8_t* d = dicts + (size_t)pack * (kDictBytes + 256) + 64;
+        const uint32_t lines = (kDictBytes + 127u) >> 7, per = (lines + NW - 1u) / NW;  // lines per warmer
+        constexpr uint32_t NL = (4385 / NW + 255) / 256 + 1;
+        uint32_t v[NL];
+#pragma unroll
+        for (uint32_t i = 0; i < NL; i++) {
+            const uint32_t idx = threadIdx.x + i * 256u, line = j * per + idx;
+            v[i] = *(const uint32_t*)(d + 128ull * ((idx < per && line < lines) ? line : 0u));
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < NL; i++) asm volatile("" ::"v"(v[i]));
+        return;
+    }
+    if (k < (uint32_t)LAG || k - LAG >= npx) return;
+    const uint32_t kk = k - LAG, pack = kk * 8u + ((xcd + kk) & 7u);
+    tiles_body<F>(j - NW, pack, 64u, dicts, doffs, ids, out, npacks, pack_out_stride);
+}
+
 template <int F, int LAG>
 __global__ __launch_bounds__(256, 6) void k_pipe(const uint8_t* __restrict__ dicts, const uint32_t* __restrict__ doffs,
                                                  const uint16_t* __restrict__ ids, uint8_t* __restrict__ out, uint32_t npacks,
@@ -441,6 +533,52 @@ int main() {
     RUN(FULL | ZIPF | PREFW, var_bytes, "  Zipf ids, 1024-row tiles + warm-up of four consecutive shares");
     RUN(FULL | ZIPF | PREFS | TRIM | ALIGN128, var_bytes, "  Zipf ids, 1024-row tiles + four spread shares + trim + aligned grid");
     RUN(FULL | ZIPF | PREFL | TRIM | ALIGN128, var_bytes, "  Zipf ids, 1024-row tiles + line warm-up + trim + aligned grid");
+    RUN(FULL | ZIPF | FEWDICTS | PREFL, var_bytes, "  Zipf ids, 1024-row tiles, four dictionaries in all + line warm-up (of resident lines)");
+    RUN(FULL | ZIPF | FEWDICTS | PREFL | COLDWARM, var_bytes, "  Zipf ids, 1024-row tiles, four dictionaries in all + line warm-up reading the COLD per-pack dictionaries");
+    RUN(FULL | ZIPF | FEWDICTS | PREFL | COLDWARM | TILE256 | TRIM | ALIGN128, var_bytes, "  the same with 256-row tiles + trim + aligned grid");
+    RUN(FULL | ZIPF | PREFL | LATE, var_bytes, "  Zipf ids, 1024-row tiles + line warm-up nobody waits for separately");
+    RUN(FULL | PREFL | LATE, var_bytes, "  uniform ids, 1024-row tiles + line warm-up nobody waits for separately");
+    RUN(FULL | ZIPF | FEWDICTS | PREFL | COLDWARM | LATE, var_bytes, "  Zipf ids, four dictionaries in all + cold warm-up loads nobody waits for separately");
+    RUN(FULL | ZIPF | PREFL | LATE | TILE256 | TRIM | ALIGN128, var_bytes, "  Zipf ids, 256-row tiles + trim + aligned + line warm-up (own share) nobody waits for separately");
+    for (uint32_t region : {2u << 20, 16u << 20, 64u << 20, 256u << 20, 512u << 20}) {
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_cold_region), &region, 4));
+        char nm[160]; snprintf(nm, sizeof nm, "  four dictionaries in all + warm-up loads spread over a region of %u MB", region >> 20);
+        RUN(FULL | ZIPF | FEWDICTS | PREFL | COLDWARM, var_bytes, nm);
+    }
+    for (uint32_t region : {96u << 20, 128u << 20, 192u << 20}) {
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_cold_region), &region, 4));
+        char nm[160]; snprintf(nm, sizeof nm, "  four dictionaries in all + warm-up loads spread over a region of %u MB", region >> 20);
+        RUN(FULL | ZIPF | FEWDICTS | PREFL | COLDWARM, var_bytes, nm);
+    }
+    for (uint32_t spread : {2u, 4u, 8u}) {
+        const uint32_t region = 60u << 20;  // 60 MB of lines (the spare 2 MB at the end absorb a share that starts at the region's last line)
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_cold_region), &region, 4));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_cold_spread), &spread, 4));
+        char nm[160]; snprintf(nm, sizeof nm, "  four dictionaries in all + warm-up loads: 60 MB of lines, %u x 128 bytes apart (span %u MB)", spread, 60 * spread);
+        RUN(FULL | ZIPF | FEWDICTS | PREFL | COLDWARM, var_bytes, nm);
+    }
+    { uint32_t zero = 0; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_cold_region), &zero, 4)); CK(hipMemcpyToSymbol(HIP_SYMBOL(g_cold_spread), &zero, 4)); }
+#define RUNW(F, LAG, NW, name) timeit(name, var_bytes, [&] { hipLaunchKernelGGL((k_warmers<(F), LAG, NW>), dim3(8u * (npacks / 8u + LAG) * (NW + 64u)), dim3(256), 0, 0, dicts, doffs, zids, out, npacks, pack_out_stride); })
+    RUNW(FULL | ZIPF | TILE256 | TRIM | ALIGN128, 1, 16, "  WARMERS: 16 workgroups read a pack's dictionary and exit, its 64 tile workgroups follow one pack later");
+    RUNW(FULL | ZIPF | TILE256 | TRIM | ALIGN128, 2, 16, "  warmers, tile workgroups two packs behind");
+    RUNW(FULL | ZIPF | TILE256 | TRIM | ALIGN128, 3, 16, "  warmers, tile workgroups three packs behind");
+    RUNW(FULL | ZIPF | TILE256 | TRIM | ALIGN128, 2, 4, "  4 warmers per pack, tile workgroups two packs behind");
+    RUNW(FULL | ZIPF | TILE256 | TRIM | ALIGN128, 2, 2, "  2 warmers per pack, tile workgroups two packs behind");
+    RUNW(FULL | ZIPF | TILE256 | TRIM | ALIGN128, 4, 2, "  2 warmers per pack, tile workgroups four packs behind");
+    RUNW(FULL | ZIPF | TILE256 | TRIM | ALIGN128, 0, 16, "  warmers right before the pack's own tile workgroups");
+    for (uint32_t sb : {64u, 128u, 256u}) {
+        for (int mode = 0; mode < 3; mode++) {
+            char nm[200]; snprintf(nm, sizeof nm, "  sub-batches of %u packs (1024-row tiles, line warm-up)%s", sb,
+                                   mode == 0 ? "" : (mode == 1 ? ", each preceded by a kernel that WRITES its dictionaries" : ", each preceded by a kernel that READS its dictionaries"));
+            timeit(nm, var_bytes, [&] {
+                for (uint32_t p0 = 0; p0 < npacks; p0 += sb) {
+                    if (mode == 1) hipLaunchKernelGGL((k_fill_or_touch<true>), dim3(16, sb), dim3(256), 0, 0, dicts, npacks, p0);
+                    if (mode == 2) hipLaunchKernelGGL((k_fill_or_touch<false>), dim3(16, sb), dim3(256), 0, 0, dicts, npacks, p0);
+                    hipLaunchKernelGGL((k_tiles_sub<FULL | ZIPF | PREFL>), dim3(16, sb), dim3(256), 0, 0, dicts, doffs, zids, out, npacks, pack_out_stride, p0);
+                }
+            });
+        }
+    }
     RUN(FULL | ZIPF | PREFW | TILE256, var_bytes, "  Zipf ids + 256-row tiles + warm-up of four consecutive shares per workgroup");
     RUN(FULL | ZIPF | PREFS | TILE256, var_bytes, "  Zipf ids + 256-row tiles + warm-up of four spread shares per workgroup");
     RUN(FULL | PREFS | TILE256, var_bytes, "  uniform ids + 256-row tiles + warm-up of four spread shares");
