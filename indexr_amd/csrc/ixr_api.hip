@@ -241,12 +241,12 @@ extern "C" void ixr_plan_destroy(ixr_plan* plan) {
 namespace {
 struct EnvSwitches {
     std::atomic<int> split_str{0};       // IXR_SPLIT_STR=1: string rows by k_str_index + k_str_copy instead of k_str_bases + k_str_fused
-    std::atomic<int> slice{0};           // IXR_SLICE=1: sorted numeric dictionaries taken in order are decoded per tile (k_dict_slice)
+    std::atomic<int> slice{1};           // IXR_SLICE=0: sorted numeric dictionaries taken in order go through scratch like the others (default: decoded per tile, the slice path of k_dict_num)
     std::atomic<int> lane_walk_from{0};  // IXR_LANE_WALK_FROM=n: packs per launch from which the lane walker replaces the window walker
     EnvSwitches() {
         if (const char* e = getenv("IXR_SPLIT_STR")) split_str = e[0] == '1';
         if (const char* e = getenv("IXR_LANE_WALK_FROM")) lane_walk_from = atoi(e);
-        if (const char* e = getenv("IXR_SLICE")) slice = e[0] == '1';
+        if (const char* e = getenv("IXR_SLICE")) slice = e[0] != '0';
     }
 };
 EnvSwitches& env_switches() {
@@ -466,8 +466,6 @@ static int32_t run_group_rows(ixr_plan* pl, Timer& T, Timer& TB, LaunchCtx& c, L
     run_group_front_num(pl, TN, cn, g);
     TN.run("k_dict_num<u32>", g.cnt[L_N32], [&] { launch_dict_num(cn, L + g.off[L_N32], g.cnt[L_N32], 32); });
     TN.run("k_dict_num<u64>", g.cnt[L_N64], [&] { launch_dict_num(cn, L + g.off[L_N64], g.cnt[L_N64], 64); });
-    TN.run("k_dict_slice<u32>", pl->slice ? g.cnt[L_N32] : 0, [&] { launch_dict_slice(cn, L + g.off[L_N32], g.cnt[L_N32], 32); });
-    TN.run("k_dict_slice<u64>", pl->slice ? g.cnt[L_N64] : 0, [&] { launch_dict_slice(cn, L + g.off[L_N64], g.cnt[L_N64], 64); });
     TN.run("k_copy_raw", g.cnt[L_RAW], [&] { launch_copy_raw(cn, L + g.off[L_RAW], g.cnt[L_RAW]); });
     run_group_front_str(pl, T, c, g, 0);
     if (pl->fused_str) {
@@ -755,8 +753,6 @@ static int32_t decode_small(const ixr_pack_desc* descs, int32_t n_packs, const v
         if (!use_ds) {
             launch_dict_num(c, n32, counts[SL_N32], 32);
             launch_dict_num(c, n64, counts[SL_N64], 64);
-            launch_dict_slice(c, n32, counts[SL_N32], 32);
-            launch_dict_slice(c, n64, counts[SL_N64], 64);
             launch_copy_raw(c, raw, counts[SL_RAW]);
         }
         launch_delta(c, str, counts[SL_STR], 32, 2);
@@ -804,8 +800,7 @@ static void attribute_bytes(ixr_plan* pl, const std::vector<PackMeta>& metas, st
             case K_DELTA_NUM: by[w32 ? "k_delta<u32>" : "k_delta<u64>"] += ps + ds; break;
             case K_DICT_NUM:
                 by[w32 ? "k_delta<u32>" : "k_delta<u64>"] += m.ids_off;                     // header + entries
-                if (m.sliced) by[w32 ? "k_dict_slice<u32>" : "k_dict_slice<u64>"] += (ps - m.ids_off) + ds;
-                else by[w32 ? "k_dict_num<u32>" : "k_dict_num<u64>"] += (ps - m.ids_off) + ds;   // id stream in, rows out
+                by[w32 ? "k_dict_num<u32>" : "k_dict_num<u64>"] += (ps - m.ids_off) + ds;   // id stream in, rows out
                 break;
             case K_DICT_STR: {
                 const uint64_t index = 4 * (n + 1), body = ds > index ? ds - index : 0;

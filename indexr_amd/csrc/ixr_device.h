@@ -109,7 +109,7 @@ struct PackMeta {
     uint32_t front_blocks;  // front-coded dictionary: number of 64-string blocks decoded in parallel (0 = serial path)
     uint32_t front_stride;  // columns per block row of the block-summary array (max_len rounded up to 64)
     uint32_t sliced;        // numeric dictionary pack whose rows ask for the entries in order: no dictionary in scratch, only one
-                            // value per 128-entry block (k_delta), the rows come from k_dict_slice
+                            // record per 128-entry block (k_delta), the rows come from the slice path of k_dict_num
     StreamDesc s[2];
 };
 

@@ -1049,11 +1049,13 @@ template <typename U> __device__ __forceinline__ U wave_incl_scan(U v) {
 // Also copies plain (uncompressed) dictionary entries into the aligned scratch dictionary (PlainCodec.java:48-70).
 // ---------------------------------------------------------------------------------------------------------------
 // How the numeric dictionary packs are shared out between the row kernels, by the size and use of their dictionaries:
-// 2 to 64 KB: looked up in LDS (k_dict_lds); larger ones whose rows ask for the entries in order: k_dict_slice; the rest
+// 2 to 64 KB: looked up in LDS (k_dict_lds); larger ones whose rows ask for the entries in order: the slice path of k_dict_num; the rest
 // (and dictionaries below 2 KB, which stay in the vector L1): gathers from the scratch dictionary (k_dict_num).
 constexpr uint32_t kDictLdsBytes = 65536, kDictLdsMinBytes = 2048;
-constexpr uint32_t kSliceBlocks = 9;      // 128-entry blocks k_dict_slice decodes per round: a stretch of 1025 entries at any alignment
+constexpr uint32_t kSliceBlocks = 9;      // 128-entry blocks the slice path of k_dict_num decodes per tile: a stretch of 1025 entries at any alignment
 constexpr uint32_t kSliceSpan = 1024;     // largest rise of the ids over a tile that one round covers
+constexpr uint32_t kSliceMaxBw = 28;      // widest mini-block of a sliced dictionary: two neighbouring entries then sit in one 8-byte load
+constexpr uint32_t kSliceFirstOff = 32768;  // sliced packs: the id of every tile's first row, behind the block records (at most 512 x 32 bytes)
 
 template <typename U, int kThreads>
 __global__ __launch_bounds__(kThreads) void k_delta(const DevPack* __restrict__ packs, const int* __restrict__ list,
@@ -1086,16 +1088,27 @@ __global__ __launch_bounds__(kThreads) void k_delta(const DevPack* __restrict__ 
 
     // A sorted dictionary whose rows ask for its entries in order (a column that grows with the row number: timestamps,
     // counters; the ids then step by 0 or 1) is not written to scratch at all: a tile of rows needs a stretch of at most
-    // kSliceSpan entries, which k_dict_slice decodes into LDS by itself from the value in front of the stretch's first
+    // kSliceSpan entries, which k_dict_num decodes into LDS by itself from the value in front of the stretch's first
     // 128-entry block.  Those values, one per block, are all this kernel leaves for such a pack.  The choice is made from the
     // id of every tile's first row (the segment records of the framing walk give it without walking the stream): they must
-    // rise from tile to tile by at most kSliceSpan.  Ids that misbehave inside a tile cost k_dict_slice extra rounds, no more.
+    // rise from tile to tile by at most kSliceSpan.  Ids that misbehave inside a tile cost k_dict_num extra rounds, no more.
     bool sliced = false;
     if (kind == K_DICT_NUM && dict_only == 2 && (uint64_t)M.entry_count * sizeof(U) > kDictLdsBytes) {
         __shared__ int s_sliced;
+        __shared__ uint32_t s_maxbw;
+        if (tid == 0) s_maxbw = 0;
+        __syncthreads();
+        {   // the widest mini-block of the entry stream (the framing walk left one word per mini-block)
+            const uint32_t* mbw = (const uint32_t*)((const int64_t*)(scratch + P.s_idx[0]) + (P.obj_count + kBlock - 1) / kBlock);
+            uint32_t mw = 0;
+            for (uint32_t i = tid; i < (s.n + kMini - 1) / kMini; i += kThreads) mw = max(mw, mbw[i] >> 24);
+            if (mw) atomicMax(&s_maxbw, mw);
+        }
+        __syncthreads();
+        const uint32_t ntiles = ((uint32_t)P.obj_count + kRleTile - 1) / kRleTile;
+        uint32_t id = M.entry_count - 1u;
         if (tid < 64) {
-            const uint32_t ntiles = ((uint32_t)P.obj_count + kRleTile - 1) / kRleTile, ec = M.entry_count, bw = M.id_bw;
-            uint32_t id = ec - 1u;
+            const uint32_t ec = M.entry_count, bw = M.id_bw;
             if ((uint32_t)tid < ntiles) {
                 const uint4 rec = ((const uint4*)(scratch + P.s_restart))[tid];
                 id = (rec.w & 1u) ? extract32(base + rec.x, ((uint32_t)tid * kRleTile - rec.y) * bw, bw) : (rec.w >> 1);
@@ -1105,12 +1118,14 @@ __global__ __launch_bounds__(kThreads) void k_delta(const DevPack* __restrict__ 
             const bool ok = (uint32_t)tid >= ntiles || (id < ec && next >= id && next - id <= kSliceSpan);
             const uint64_t no = __builtin_amdgcn_ballot_w64(!ok);
             if (tid == 0) {
-                s_sliced = no == 0;
-                if (no == 0) metas[pi].sliced = 1;
+                s_sliced = no == 0 && s_maxbw <= kSliceMaxBw && s.n == ec;
+                if (s_sliced) metas[pi].sliced = 1;
             }
         }
         __syncthreads();
         sliced = s_sliced != 0;
+        // the first id of every tile: where k_dict_num starts decoding for the tile
+        if (sliced && (uint32_t)tid < ntiles && tid < 64) ((uint32_t*)(scratch + P.s_dict + kSliceFirstOff))[tid] = id;
     }
 
     U* dst;
@@ -1225,8 +1240,15 @@ __global__ __launch_bounds__(kThreads) void k_delta(const DevPack* __restrict__ 
         }
         const U pre = carry + wprefix + (incl - d[V - 1]);
         if (sliced) {
-            // the value in front of every 128-entry block (`pre` is the entry before this thread's first one)
-            if ((i0 & (kBlock - 1)) == 0 && i0 < n) dst[i0 >> 7] = pre;
+            // one 32-byte record per 128-entry block: its four mini-block words (position | width << 24), its minimum, and the
+            // value in front of it (`pre` is the entry before this thread's first one)
+            if ((i0 & (kBlock - 1)) == 0 && i0 < n) {
+                const uint32_t b = i0 >> 7;
+                uint4* rec = (uint4*)(scratch + P.s_dict) + 2 * b;
+                const uint64_t md = (uint64_t)min_delta[b], pv = (uint64_t)pre;
+                rec[0] = make_uint4(mb[4 * b], mb[4 * b + 1], mb[4 * b + 2], mb[4 * b + 3]);
+                rec[1] = make_uint4((uint32_t)md, (uint32_t)(md >> 32), (uint32_t)pv, (uint32_t)(pv >> 32));
+            }
         } else if (i0 + V - 1 < n) {
             if constexpr (sizeof(U) == 4) {
 #pragma unroll
@@ -1376,61 +1398,212 @@ template <typename U> __device__ __forceinline__ bool dict_in_lds(uint32_t entry
 // ---------------------------------------------------------------------------------------------------------------
 // k_dict_num: numeric dictionary packs.  One wave per tile of kRleTile rows: out[i] = dict[id[i]]
 // (DictStruct.decodeInts/Longs/Floats/Doubles, indexr-common/.../data/DictStruct.java:57-95).
+//
+// Packs marked `sliced` by k_delta (sorted dictionary, rows that ask for its entries in order, no mini-block of the entry
+// stream wider than kSliceMaxBw bits) have no dictionary in scratch.  k_delta left, per 128-entry block, a 32-byte record
+// (the block's four mini-block words, its minimum, the value in front of it) and, per tile, the id of the tile's first row.
+// The wave reads the records of the kSliceBlocks blocks from that id on and then the packed bits of those blocks -- two
+// neighbouring entries per lane and block in ONE 8-byte load -- while it expands the tile's ids; it decodes the blocks
+// into LDS, kRound at a time (every block starts from its own value, so they are independent: bits, + minDelta, one wave
+// scan per block; DeltaCodec.decodeLongsBlock, DeltaCodec.java:216-231) and looks the rows up there.  Rows whose ids lie
+// outside that stretch (ids that jump inside a tile) are produced afterwards, one 128-entry block at a time: any id
+// stream decodes correctly, only not quickly.
 // ---------------------------------------------------------------------------------------------------------------
 template <typename U>
-__global__ __launch_bounds__(256) void k_dict_num(const DevPack* __restrict__ packs, const int* __restrict__ list,
+__device__ __forceinline__ void slice_two(uint64_t w, uint32_t sh, uint32_t bw, U md, bool has0, bool has1, U& a0, U& a1) {
+    // two neighbouring entries out of the 8 bytes that hold them: sh <= 7, bw <= kSliceMaxBw, so sh + 2 * bw <= 63
+    const uint64_t mask = (1ull << bw) - 1ull;
+    a0 = has0 ? (U)((w >> sh) & mask) + md : (U)0;
+    a1 = has1 ? (U)((w >> (sh + bw)) & mask) + md : (U)0;
+}
+template <typename U>
+__device__ __forceinline__ void store_pair(U* p, U a, U b) {  // p is 2 * sizeof(U) aligned; streaming store
+    if constexpr (sizeof(U) == 4) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 t = {(uint32_t)a, (uint32_t)b};
+        __builtin_nontemporal_store(t, (u32x2*)p);
+    } else {
+        typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+        u64x2 t = {(uint64_t)a, (uint64_t)b};
+        __builtin_nontemporal_store(t, (u64x2*)p);
+    }
+}
+template <typename U>
+__global__ __launch_bounds__(256, 6) void k_dict_num(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                   PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                   uint8_t* __restrict__ out, const uint8_t* __restrict__ scratch) {
-    __shared__ uint16_t s_ids[4][kRleTile];
-    __shared__ __align__(16) uint8_t s_win[4][kWinAlloc];
+    // per wave: the stream window and the id tile; sliced packs decode their stretch of the dictionary over both once the ids
+    // are in registers, kRound blocks at a time, and keep the stretch's block records behind them
+    constexpr uint32_t kRound = sizeof(U) == 8 ? 6 : 9;
+    constexpr uint32_t kMainLds = kWinAlloc + 2 * kRleTile;
+    static_assert(kRound * kBlock * sizeof(U) <= kMainLds && kWinAlloc % 16 == 0, "a round's entries fit the window and the id tile");
+    __shared__ __align__(16) uint8_t smem[4][kMainLds + 32 * kSliceBlocks];
     TileCtx t;
     if (!tile_ctx(t, packs, list, metas, K_DICT_NUM, 0)) return;
     if (dict_in_lds<U>(t.ec)) return;  // k_dict_lds takes this pack
     const DevPack& P = packs[t.pi];
     const PackMeta& M = metas[t.pi];
-    if (M.sliced) return;              // k_dict_slice takes this pack
-    const U* __restrict__ dict = (const U*)(scratch + P.s_dict);
-    const Warm warm = warm_issue(scratch + P.s_dict, t.ec * (uint32_t)sizeof(U), t.tile >> 2, gridDim.x, t.ec, t.n);
+    const bool sliced = __builtin_amdgcn_readfirstlane((int)M.sliced) != 0;
+    const uint8_t* base = in + P.in_off;
+    const uint32_t psz = (uint32_t)P.pack_size, ec = t.ec;
+    uint8_t* wl = smem[threadIdx.x >> 6];
+    uint16_t* ids = (uint16_t*)(wl + kWinAlloc);
     U* __restrict__ dst = (U*)(out + P.out_off) + t.tile_start;
-    uint16_t* ids = s_ids[threadIdx.x >> 6];
-    const uint4 seg = ((const uint4*)(scratch + P.s_restart))[t.tile];
-    Win w;
-    w.init(in + P.in_off, (uint32_t)P.pack_size, s_win[threadIdx.x >> 6]);
-    rle_tile_expand(w, M.id_bw, M.ids_off + 4 + M.ids_len, seg, t.tile_start, t.tile_end, ids);
     const uint32_t cnt = t.tile_end - t.tile_start, lane = threadIdx.x & 63;
-    // a lane takes two neighbouring rows of every 128: ids come out of LDS two at a time, results leave as 8 / 16 byte
-    // stores, and the 16 gathers are all in flight before the first store
+    const uint4 seg = ((const uint4*)(scratch + P.s_restart))[t.tile];
+
+    if (!sliced) {
+        const U* __restrict__ dict = (const U*)(scratch + P.s_dict);
+        const Warm warm = warm_issue(scratch + P.s_dict, ec * (uint32_t)sizeof(U), t.tile >> 2, gridDim.x, ec, t.n);
+        Win w;
+        w.init(base, psz, wl);
+        rle_tile_expand(w, M.id_bw, M.ids_off + 4 + M.ids_len, seg, t.tile_start, t.tile_end, ids);
+        // a lane takes two neighbouring rows of every 128: ids come out of LDS two at a time, results leave as 8 / 16 byte
+        // stores, and the 16 gathers are all in flight before the first store
+        uint32_t id[16];
+        bool bad = false;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t r = q * 128 + 2 * lane;
+            const uint32_t two = ((const uint32_t*)ids)[q * 64 + lane];
+            id[2 * q] = r < cnt ? (two & 0xFFFFu) : 0u;
+            id[2 * q + 1] = r + 1 < cnt ? (two >> 16) : 0u;
+            if (id[2 * q] >= ec) { bad = true; id[2 * q] = 0; }
+            if (id[2 * q + 1] >= ec) { bad = true; id[2 * q + 1] = 0; }
+        }
+        U v[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = dict[id[q]];
+        warm_done(warm);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t r = q * 128 + 2 * lane;
+            // streaming (non-temporal) stores: the rows are not read again here and must not push the dictionary out of L2
+            if (r + 1 < cnt) store_pair<U>(dst + r, v[2 * q], v[2 * q + 1]);
+            else if (r < cnt) dst[r] = v[2 * q];
+        }
+        if (bad) metas[t.pi].status = E_CORRUPT;
+        return;
+    }
+
+    // ---- sliced pack.  The stretch: kSliceBlocks blocks from the block of the tile's first id on; its records are requested first
+    const uint32_t nblk = (ec + kBlock - 1) / kBlock;  // >= 1: sliced packs have more than 64 KB of entries
+    const uint4* __restrict__ recs = (const uint4*)(scratch + P.s_dict);  // two uint4 per block, nblk blocks
+    const uint32_t first = min(uniform_load((const uint32_t*)(scratch + P.s_dict + kSliceFirstOff) + t.tile), ec - 1u);
+    const uint32_t bA = first >> 7, nb = min(kSliceBlocks, nblk - bA);  // bA < nblk, nb >= 1
+    uint4 myrec = make_uint4(0, 0, 0, 0);
+    if (lane < 2u * nb) myrec = recs[2u * bA + lane];  // 2 * bA + lane < 2 * nblk
     uint32_t id[16];
     bool bad = false;
+    {
+        Win w;
+        w.init(base, psz, wl);
+        rle_tile_expand(w, M.id_bw, M.ids_off + 4 + M.ids_len, seg, t.tile_start, t.tile_end, ids);
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const uint32_t r = q * 128 + 2 * lane;
-        const uint32_t two = ((const uint32_t*)ids)[q * 64 + lane];
-        id[2 * q] = r < cnt ? (two & 0xFFFFu) : 0u;
-        id[2 * q + 1] = r + 1 < cnt ? (two >> 16) : 0u;
-        if (id[2 * q] >= t.ec) { bad = true; id[2 * q] = 0; }
-        if (id[2 * q + 1] >= t.ec) { bad = true; id[2 * q + 1] = 0; }
+        for (int q = 0; q < 8; q++) {
+            const uint32_t r = q * 128 + 2 * lane;
+            const uint32_t two = ((const uint32_t*)ids)[q * 64 + lane];
+            id[2 * q] = r < cnt ? (two & 0xFFFFu) : 0xFFFFFFFFu;      // rows past the tile's end take part in nothing
+            id[2 * q + 1] = r + 1 < cnt ? (two >> 16) : 0xFFFFFFFFu;
+            if (r < cnt && id[2 * q] >= ec) { bad = true; id[2 * q] = 0xFFFFFFFFu; }
+            if (r + 1 < cnt && id[2 * q + 1] >= ec) { bad = true; id[2 * q + 1] = 0xFFFFFFFFu; }
+        }
     }
-    U v[16];
+    U* slice = (U*)wl;
+    uint4* lrec = (uint4*)(wl + kMainLds);  // [2 * kSliceBlocks]
+    if (lane < 2u * kSliceBlocks) lrec[lane] = myrec;
+    Win::wave_lds_sync();  // window and id tile are dead (their memory becomes the dictionary stretch); the records are in place
+    const uint32_t e0 = 2 * lane;  // this lane's two entries of every block
+    // the packed bits of the stretch: one 8-byte load per lane and block, all issued before any is used
+    uint64_t bits[kSliceBlocks];
 #pragma unroll
-    for (int q = 0; q < 16; q++) v[q] = dict[id[q]];
-    warm_done(warm);
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const uint32_t r = q * 128 + 2 * lane;
-        // streaming (non-temporal) stores: the rows are not read again here and must not push the dictionary out of L2
-        if (r + 1 < cnt) {
-            if constexpr (sizeof(U) == 4) {
-                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                u32x2 t = {(uint32_t)v[2 * q], (uint32_t)v[2 * q + 1]};
-                __builtin_nontemporal_store(t, (u32x2*)(dst + r));
-            } else {
-                typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
-                u64x2 t = {(uint64_t)v[2 * q], (uint64_t)v[2 * q + 1]};
-                __builtin_nontemporal_store(t, (u64x2*)(dst + r));
+    for (uint32_t k = 0; k < kSliceBlocks; k++) {
+        bits[k] = 0;
+        if (k < nb) {
+            const uint32_t word = ((const uint32_t*)(lrec + 2 * k))[lane >> 4];
+            const uint32_t bw = word >> 24, in_blk = min((uint32_t)kBlock, ec - (bA + k) * kBlock);
+            if (e0 < in_blk && bw) {
+                // inside the pack (the framing walk checked the mini-block) or, for a block's last entries, its 16 bytes of slack
+                const uint32_t at = min((word & 0xFFFFFFu) + (((e0 & 31u) * bw) >> 3), psz);
+                __builtin_memcpy(&bits[k], base + at, 8);
             }
         }
-        else if (r < cnt) dst[r] = v[2 * q];
+    }
+    uint32_t left = 0;  // bit q: row q of this lane is still to do
+#pragma unroll
+    for (int q = 0; q < 16; q++)
+        if (id[q] != 0xFFFFFFFFu) left |= 1u << q;
+    // rows [c0, c1) of the dictionary are in LDS from slice[0] on: serve the rows that ask for them
+    auto serve = [&](uint32_t c0, uint32_t c1) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t r = q * 128 + 2 * lane;
+            const uint32_t ia = id[2 * q], ib = id[2 * q + 1];
+            const bool ina = ((left >> (2 * q)) & 1u) && ia >= c0 && ia < c1, inb = ((left >> (2 * q + 1)) & 1u) && ib >= c0 && ib < c1;
+            const U va = ina ? slice[ia - c0] : (U)0, vb = inb ? slice[ib - c0] : (U)0;
+            if (ina && inb) store_pair<U>(dst + r, va, vb);
+            else {
+                if (ina) dst[r] = va;
+                if (inb) dst[r + 1] = vb;
+            }
+            if (ina) left &= ~(1u << (2 * q));
+            if (inb) left &= ~(2u << (2 * q));
+        }
+    };
+    // ---- decode kRound blocks at a time: + minimum, scan from the block's own value, into LDS; then the lookups
+#pragma unroll
+    for (uint32_t k0 = 0; k0 < kSliceBlocks; k0 += kRound) {
+        if (k0 < nb) {
+            if (k0) Win::wave_lds_sync();  // the round before has been read
+#pragma unroll
+            for (uint32_t k = k0; k < k0 + kRound && k < kSliceBlocks; k++) {
+                if (k < nb) {
+                    const uint4 r1 = lrec[2 * k + 1];
+                    const uint32_t word = ((const uint32_t*)(lrec + 2 * k))[lane >> 4];
+                    const uint32_t bw = min(word >> 24, kSliceMaxBw), in_blk = min((uint32_t)kBlock, ec - (bA + k) * kBlock);
+                    const U md = (U)((uint64_t)r1.x | ((uint64_t)r1.y << 32)), pv = (U)((uint64_t)r1.z | ((uint64_t)r1.w << 32));
+                    U a0, a1;
+                    slice_two<U>(bits[k], ((e0 & 31u) * bw) & 7u, bw, md, e0 < in_blk, e0 + 1 < in_blk, a0, a1);
+                    const U two = a0 + a1;
+                    const U before = pv + wave_incl_scan<U>(two) - two;
+                    U* d = slice + (k - k0) * kBlock + e0;
+                    d[0] = before + a0;
+                    d[1] = before + two;
+                }
+            }
+            Win::wave_lds_sync();
+            serve((bA + k0) * kBlock, (bA + min(k0 + kRound, nb)) * kBlock);
+        }
+    }
+    // ---- rows outside the stretch: the block of the smallest id still to do, decoded into the first 128 entries of the LDS
+    // stretch, serves every row that asks for it; at most one round per block of the dictionary
+    while (__builtin_amdgcn_ballot_w64(left != 0)) {
+        uint32_t lo = 0xFFFFFFFFu;
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+            if ((left >> q) & 1u) lo = min(lo, id[q]);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) lo = min(lo, (uint32_t)__shfl_xor((int)lo, d));
+        const uint32_t b = min((uint32_t)__builtin_amdgcn_readfirstlane(lo) >> 7, nblk - 1u);
+        const uint4 r0 = recs[2u * b], r1 = recs[2u * b + 1u];
+        const uint32_t wsel = lane >> 4;
+        const uint32_t word = wsel == 0 ? r0.x : (wsel == 1 ? r0.y : (wsel == 2 ? r0.z : r0.w));
+        const uint32_t bw = min(word >> 24, kSliceMaxBw), in_blk = min((uint32_t)kBlock, ec - b * kBlock);
+        uint64_t w = 0;
+        if (e0 < in_blk && bw) {
+            const uint32_t at = min((word & 0xFFFFFFu) + (((e0 & 31u) * bw) >> 3), psz);
+            __builtin_memcpy(&w, base + at, 8);
+        }
+        const U md = (U)((uint64_t)r1.x | ((uint64_t)r1.y << 32)), pv = (U)((uint64_t)r1.z | ((uint64_t)r1.w << 32));
+        U a0, a1;
+        slice_two<U>(w, ((e0 & 31u) * bw) & 7u, bw, md, e0 < in_blk, e0 + 1 < in_blk, a0, a1);
+        const U two = a0 + a1;
+        const U before = pv + wave_incl_scan<U>(two) - two;
+        Win::wave_lds_sync();  // the round before has been read
+        slice[e0] = before + a0;
+        slice[e0 + 1] = before + two;
+        Win::wave_lds_sync();
+        serve(b * kBlock, b * kBlock + kBlock);  // the row with the smallest id is among them: every round resolves a row
     }
     if (bad) metas[t.pi].status = E_CORRUPT;
 }
@@ -1500,135 +1673,6 @@ __global__ __launch_bounds__(1024) void k_dict_lds(const DevPack* __restrict__ p
         }
     }
     if (bad) metas[pi].status = E_CORRUPT;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// k_dict_slice: numeric dictionary packs marked `sliced` by k_delta (sorted dictionary, rows that ask for its entries in
-// order).  One wave per tile of kRleTile rows: expands the tile's ids, takes their range [lo, hi], decodes the 128-entry
-// blocks of the DELTA-coded entry stream that cover it into LDS -- every block starts from the value k_delta left for it,
-// so the blocks are independent of each other: bit extraction, + minDelta, one wave scan per block
-// (DeltaCodec.decodeLongsBlock, DeltaCodec.java:216-231) -- and looks the rows up there
-// (DictStruct.decodeLongs, DictStruct.java:66-80).  The dictionary itself never exists in memory.  A tile whose ids span
-// more than kSliceBlocks blocks takes further rounds over the following blocks; every row is produced in the round that
-// holds its entry, so any id stream decodes correctly, only not quickly.
-// ---------------------------------------------------------------------------------------------------------------
-template <typename U>
-__global__ __launch_bounds__(256) void k_dict_slice(const DevPack* __restrict__ packs, const int* __restrict__ list,
-                                                    PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
-                                                    uint8_t* __restrict__ out, const uint8_t* __restrict__ scratch) {
-    // per wave: the stream window and the id tile while the ids are expanded, then the decoded stretch of the dictionary
-    constexpr uint32_t kSliceBytes = kSliceBlocks * kBlock * (uint32_t)sizeof(U);
-    constexpr uint32_t kWaveLds = (SmallWin::kAlloc + 2 * kRleTile > kSliceBytes ? SmallWin::kAlloc + 2 * kRleTile : kSliceBytes) + 16;
-    __shared__ __align__(16) uint8_t smem[4][kWaveLds];
-    TileCtx t;
-    if (!tile_ctx(t, packs, list, metas, K_DICT_NUM, 0)) return;
-    const PackMeta& M = metas[t.pi];
-    if (!M.sliced) return;
-    const DevPack& P = packs[t.pi];
-    const uint8_t* base = in + P.in_off;
-    const uint32_t lane = threadIdx.x & 63, cnt = t.tile_end - t.tile_start, ec = t.ec;
-    uint8_t* wl = smem[threadIdx.x >> 6];
-    U* __restrict__ dst = (U*)(out + P.out_off) + t.tile_start;
-    // ---- the tile's ids: 16 per lane, two neighbouring rows of every 128 (as k_dict_num)
-    uint32_t id[16];
-    bool bad = false;
-    {
-        uint16_t* ids = (uint16_t*)(wl + SmallWin::kAlloc);
-        SmallWin w;
-        w.init(base, (uint32_t)P.pack_size, wl);
-        rle_tile_expand(w, M.id_bw, M.ids_off + 4 + M.ids_len, uniform_load((const uint4*)(scratch + P.s_restart) + t.tile), t.tile_start,
-                        t.tile_end, ids);
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const uint32_t r = q * 128 + 2 * lane;
-            const uint32_t two = ((const uint32_t*)ids)[q * 64 + lane];
-            id[2 * q] = r < cnt ? (two & 0xFFFFu) : 0xFFFFFFFFu;      // rows past the tile's end take part in nothing
-            id[2 * q + 1] = r + 1 < cnt ? (two >> 16) : 0xFFFFFFFFu;
-            if (r < cnt && id[2 * q] >= ec) { bad = true; id[2 * q] = 0xFFFFFFFFu; }
-            if (r + 1 < cnt && id[2 * q + 1] >= ec) { bad = true; id[2 * q + 1] = 0xFFFFFFFFu; }
-        }
-        SmallWin::wave_lds_sync();  // window and id tile are dead: their memory becomes the dictionary stretch
-    }
-    uint32_t lo = 0xFFFFFFFFu, hi = 0;
-#pragma unroll
-    for (int q = 0; q < 16; q++)
-        if (id[q] != 0xFFFFFFFFu) { lo = min(lo, id[q]); hi = max(hi, id[q]); }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        lo = min(lo, (uint32_t)__shfl_xor((int)lo, d));
-        hi = max(hi, (uint32_t)__shfl_xor((int)hi, d));
-    }
-    lo = __builtin_amdgcn_readfirstlane(lo);
-    hi = __builtin_amdgcn_readfirstlane(hi);
-    // ---- the entry stream's index (left by the framing walk) and the block values (left by k_delta)
-    const int64_t* min_delta = (const int64_t*)(scratch + P.s_idx[0]);
-    const uint32_t* mb = (const uint32_t*)(min_delta + (P.obj_count + kBlock - 1) / kBlock);
-    const U* bases = (const U*)(scratch + P.s_dict);
-    U* slice = (U*)wl;
-    U v[16];
-#pragma unroll
-    for (int q = 0; q < 16; q++) v[q] = 0;
-    if (lo <= hi) {
-        const uint32_t nblk = (ec + kBlock - 1) / kBlock;
-        for (uint32_t b0 = lo >> 7; b0 <= (hi >> 7); b0 += kSliceBlocks) {
-            const uint32_t nb = min(kSliceBlocks, min(nblk, (hi >> 7) + 1u) - b0);  // wave-uniform
-            // a lane takes two neighbouring entries of every block (one mini-block header serves both); all loads first
-            uint32_t hdr[kSliceBlocks];
-            U md[kSliceBlocks], pv[kSliceBlocks];
-            const uint32_t e0 = 2 * lane;
-#pragma unroll
-            for (uint32_t k = 0; k < kSliceBlocks; k++) {
-                const uint32_t b = min(b0 + k, nblk - 1);
-                hdr[k] = mb[b * 4 + (lane >> 4)];
-                md[k] = (U)min_delta[b];
-                pv[k] = bases[b];
-            }
-            U a0[kSliceBlocks], a1[kSliceBlocks];
-#pragma unroll
-            for (uint32_t k = 0; k < kSliceBlocks; k++) {
-                const uint32_t b = min(b0 + k, nblk - 1);
-                const uint32_t bw = hdr[k] >> 24, in_blk = min((uint32_t)kBlock, ec - b * kBlock);
-                const uint8_t* src = base + (hdr[k] & 0xFFFFFFu);
-                // entries past the stream's end contribute nothing (their bits may lie past the pack)
-                a0[k] = e0 < in_blk ? extract<U>(src, (e0 & 31u) * bw, bw) + md[k] : (U)0;
-                a1[k] = e0 + 1 < in_blk ? extract<U>(src, ((e0 + 1) & 31u) * bw, bw) + md[k] : (U)0;
-            }
-            SmallWin::wave_lds_sync();  // the round before has been read
-#pragma unroll
-            for (uint32_t k = 0; k < kSliceBlocks; k++) {
-                if (k < nb) {
-                    const U two = a0[k] + a1[k];
-                    const U before = pv[k] + wave_incl_scan<U>(two) - two;
-                    if constexpr (sizeof(U) == 8) {
-                        *(ulonglong2*)(slice + k * kBlock + e0) = make_ulonglong2(before + a0[k], before + two);
-                    } else {
-                        *(uint2*)(slice + k * kBlock + e0) = make_uint2(before + a0[k], before + two);
-                    }
-                }
-            }
-            SmallWin::wave_lds_sync();
-            const uint32_t s0 = b0 * kBlock, s1 = s0 + nb * kBlock;
-#pragma unroll
-            for (int q = 0; q < 16; q++)
-                if (id[q] >= s0 && id[q] < s1) v[q] = slice[id[q] - s0];
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const uint32_t r = q * 128 + 2 * lane;
-        if (r + 1 < cnt) {
-            if constexpr (sizeof(U) == 4) {
-                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                u32x2 tv = {(uint32_t)v[2 * q], (uint32_t)v[2 * q + 1]};
-                __builtin_nontemporal_store(tv, (u32x2*)(dst + r));
-            } else {
-                typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
-                u64x2 tv = {(uint64_t)v[2 * q], (uint64_t)v[2 * q + 1]};
-                __builtin_nontemporal_store(tv, (u64x2*)(dst + r));
-            }
-        } else if (r < cnt) dst[r] = v[2 * q];
-    }
-    if (bad) metas[t.pi].status = E_CORRUPT;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -3543,7 +3587,7 @@ void launch_parse(const LaunchCtx& c, const int* list, int count) {
 void launch_delta(const LaunchCtx& c, const int* list, int count, int width, int streams) {
     if (count <= 0) return;
     // the kernel's mode word: 0 rows and dictionaries, 1 dictionaries only, 2 as 0 with sorted dictionaries that are taken in
-    // order left to k_dict_slice
+    // order left to the slice path of k_dict_num
     const int mode = c.dict_only ? 1 : (c.slice ? 2 : 0);
     const bool few = (long)count * streams < 512;  // fewer streams than two per compute unit: long workgroups, short chains
     if (width == 64) {
@@ -3567,12 +3611,6 @@ void launch_dict_num(const LaunchCtx& c, const int* list, int count, int width) 
         hipLaunchKernelGGL(k_dict_num<uint32_t>, dim3(gx, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out,
                            c.scratch);
     }
-}
-void launch_dict_slice(const LaunchCtx& c, const int* list, int count, int width) {
-    if (count <= 0 || !c.slice || c.dict_only) return;
-    const unsigned gx = IXR_PACK_TILES / 4;
-    if (width == 64) hipLaunchKernelGGL(k_dict_slice<uint64_t>, dim3(gx, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
-    else hipLaunchKernelGGL(k_dict_slice<uint32_t>, dim3(gx, count), dim3(256), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
 }
 void launch_copy_raw(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;

@@ -18,7 +18,7 @@ struct LaunchCtx {
     uint8_t* out;          // output arena
     uint8_t* scratch;      // scratch base of the current group
     int dict_only = 0;     // 1: build dictionaries only; packs whose decode writes straight to the output arena are skipped
-    int slice = 0;         // 1: sorted numeric dictionaries whose rows take them in order are not materialised (k_dict_slice)
+    int slice = 0;         // 1: sorted numeric dictionaries whose rows take them in order are not materialised (slice path of k_dict_num)
     int lane_walk_from = 0;  // framing walk: packs per launch from which one lane (not one wave) follows a stream; 0 = default
 };
 
@@ -85,7 +85,6 @@ int32_t set_error(int32_t code, const char* message);
 void launch_parse(const LaunchCtx& c, const int* list, int count);
 void launch_delta(const LaunchCtx& c, const int* list, int count, int width, int streams);
 void launch_dict_num(const LaunchCtx& c, const int* list, int count, int width);
-void launch_dict_slice(const LaunchCtx& c, const int* list, int count, int width);  // the packs k_delta marked `sliced`
 void launch_copy_raw(const LaunchCtx& c, const int* list, int count);
 void launch_str_dict_scan(const LaunchCtx& c, const int* list, int count);
 void launch_front_serial(const LaunchCtx& c, const int* list, int count);

@@ -1,6 +1,6 @@
 """Numeric dictionary packs whose rows ask for the sorted dictionary's entries in order (columns that grow with the row
-number).  The device does not materialise such a dictionary: k_delta leaves one value per 128-entry block and
-k_dict_slice decodes, per 1024-row tile, the stretch of entries the tile's ids span.  The choice looks at the first id of
+number).  The device does not materialise such a dictionary: k_delta leaves one record per 128-entry block and
+k_dict_num decodes, per 1024-row tile, the stretch of entries the tile's ids span.  The choice looks at the first id of
 every tile only, so the cases include id streams that pass that look and then misbehave inside the tiles, which must
 still decode to the oracle's rows (DictStruct.decodeInts/Longs/Floats/Doubles, DictStruct.java:57-95)."""
 import numpy as np
@@ -15,12 +15,13 @@ from test_oracle import rng
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _slicing_on():
-    """plans created inside these tests decode such packs per tile (the library's switch; off by default)"""
-    L.debug_switch("slice", 1)
+@pytest.fixture(autouse=True, params=[1, 0], ids=["per tile", "through scratch"])
+def _slicing(request):
+    """every case runs with plans that decode such packs per tile (the library's default) and with plans that send their
+    dictionaries through scratch like all others (the library's switch)"""
+    L.debug_switch("slice", request.param)
     yield
-    L.debug_switch("slice", 0)
+    L.debug_switch("slice", 1)
 
 
 def _growing(r, n, step, dtype):
@@ -40,6 +41,14 @@ def test_growing_columns_of_every_numeric_type():
     # every value distinct: the ids are 0, 1, 2, ...; and a descending column (ids fall: not sliced)
     cases.append(oracle_case(np.arange(65536, dtype="<i8") * 977 - 5, O.LONG, O.DICT_COMPRESS, name="long distinct"))
     cases.append(oracle_case((np.arange(65536, dtype="<i8") * -977)[:50000], O.LONG, O.DICT_COMPRESS, name="long descending"))
+    # the widest mini-block that is still decoded per tile (28 bits: two entries in one 8-byte load) and the first that is not
+    for top in (1 << 28, 1 << 29, 1 << 40):
+        cases.append(oracle_case((np.cumsum(r.integers(1, top, 65536, dtype=np.int64)) - (1 << 44)).astype("<i8"), O.LONG, O.DICT_COMPRESS,
+                                 name="long steps below 2^%d" % (top.bit_length() - 1)))
+    cases.append(oracle_case((np.cumsum(r.integers(1, 1 << 14, 65536)) - 5).astype("<i4"), O.INT, O.DICT_COMPRESS, name="int steps below 2^14"))
+    # a last block of the dictionary with few entries, and a last tile with few rows
+    cases.append(oracle_case(_growing(r, 65536 - 1000 + 3, 2001, "<i8"), O.LONG, O.DICT_COMPRESS, name="long ragged end"))
+    cases.append(oracle_case(np.repeat(_growing(r, 8200, 2001, "<i8"), 7)[:57001], O.LONG, O.DICT_COMPRESS, name="long every value seven times"))
     # wrap-around: deltas that overflow int64 inside the dictionary's DELTA stream
     big = np.sort(r.integers(-(1 << 63), (1 << 63) - 1, 30000, endpoint=True).astype("<i8"))
     cases.append(oracle_case(big, O.LONG, O.DICT_COMPRESS, name="long sorted full range"))

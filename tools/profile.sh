@@ -5,6 +5,7 @@ set -e
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$ROOT/gpurun_out/prof_$TAG
+rm -rf $O   # a tag that is run again must not add its counter files to the old ones
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python3 $ROOT/bench.py --cpu-seconds 0 --no-exclusive $*"
