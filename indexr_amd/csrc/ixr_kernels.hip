@@ -2412,11 +2412,16 @@ __global__ __launch_bounds__(kWaves * 64) void k_str_index(const DevPack* __rest
 // ids -> lengths -> one sum per tile; no barrier until all tiles are summed.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr uint32_t kBasesWaves = 16, kBasesTab = 65536;
+// Two builds: with a 64 KB length table the kernel's LDS (table, sixteen id tiles and stream windows) lets one workgroup live
+// on a compute unit; dictionaries whose lengths fit 12 KB (most: 12288 entries of up to 255 bytes) take the build with that
+// table, of which two fit.  Every pack is taken by exactly one of the two launches.
+constexpr uint32_t kBasesTabSmall = 12288;
 using BasesWin = WinT<2048>;
-__global__ __launch_bounds__(kBasesWaves * 64) void k_str_bases(const DevPack* __restrict__ packs, const int* __restrict__ list,
+template <uint32_t kTab>
+__global__ __launch_bounds__(kBasesWaves * 64, kTab == kBasesTabSmall ? 8 : 4) void k_str_bases(const DevPack* __restrict__ packs, const int* __restrict__ list,
                                                                 PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
                                                                 uint8_t* __restrict__ out, uint8_t* __restrict__ scratch) {
-    __shared__ __align__(16) uint8_t s_tab[kBasesTab];
+    __shared__ __align__(16) uint8_t s_tab[kTab];
     __shared__ __align__(16) uint8_t s_win[kBasesWaves][BasesWin::kAlloc];
     __shared__ uint16_t s_ids[kBasesWaves][kRleTile];
     __shared__ unsigned long long s_tile[IXR_PACK_TILES];
@@ -2426,6 +2431,8 @@ __global__ __launch_bounds__(kBasesWaves * 64) void k_str_bases(const DevPack* _
     if (M.status < 0 || M.kind != K_DICT_STR) return;
     const DevPack& P = packs[pi];
     const uint32_t n = (uint32_t)P.obj_count, ec = M.entry_count;
+    const uint32_t elem = M.max_len <= 255u ? 1u : 2u;
+    if (((uint64_t)ec * elem <= kBasesTabSmall) != (kTab == kBasesTabSmall)) return;  // the other build's pack
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (4ull * (n + 1) > (uint64_t)P.data_size) { if (tid == 0) M.status = E_OVERFLOW; return; }
     const uint32_t body_cap = (uint32_t)P.data_size - 4u * (n + 1);
@@ -2439,8 +2446,7 @@ __global__ __launch_bounds__(kBasesWaves * 64) void k_str_bases(const DevPack* _
     const uint32_t ntiles = (n + kRleTile - 1) / kRleTile;
     if (tid == 0) s_bad = 0;
     // ---- the length table
-    const uint32_t elem = M.max_len <= 255u ? 1u : 2u;
-    const bool tab = ec > 0 && (uint64_t)ec * elem <= kBasesTab && M.max_len <= 65535u;
+    const bool tab = ec > 0 && (uint64_t)ec * elem <= kTab && M.max_len <= 65535u;
     if (tab) {
         for (uint32_t i = tid; i < ec; i += kBasesWaves * 64) {
             const uint32_t len = doff[i + 1] - doff[i];
@@ -3649,7 +3655,8 @@ void launch_str_index(const LaunchCtx& c, const int* list, int count) {
 }
 void launch_str_bases(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_str_bases, dim3(count), dim3(kBasesWaves * 64), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+    hipLaunchKernelGGL(k_str_bases<kBasesTabSmall>, dim3(count), dim3(kBasesWaves * 64), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
+    hipLaunchKernelGGL(k_str_bases<kBasesTab>, dim3(count), dim3(kBasesWaves * 64), 0, c.stream, c.packs, list, c.metas, c.in, c.out, c.scratch);
 }
 void launch_str_fused(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;
