@@ -29,10 +29,12 @@ def short(name):
     if m.group(1) == "k_parse":  # k_parse<WinT<16384>> / k_parse<WinT<4096>>: the window walker, whatever its window
         return "k_parse"
     t = m.group(2) or ""
-    if m.group(1) == "k_dict_lds":  # the lookups of one pack class, split over two kernels by dictionary size
-        return "k_dict_num" + t.replace("unsigned int", "u32").replace("unsigned long", "u64")
     t = t.replace("unsigned int", "u32").replace("unsigned long", "u64")
-    t = re.sub(r",\s*\d+", "", t)  # k_delta<u64, 256> and k_delta<u64, 1024> are one kernel to the bench
+    t = re.sub(r",\s*\d+u?", "", t)  # k_delta<u64, 256> and k_delta<u64, 1024> are one kernel to the bench
+    if m.group(1) == "k_dict_lds":  # the lookups of one pack class, split over several kernels by dictionary size
+        return "k_dict_num" + t
+    if m.group(1) == "k_str_bases":  # two builds by the size of the length table
+        return "k_str_bases"
     return m.group(1) + t
 
 
