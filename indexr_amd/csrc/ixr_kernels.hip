@@ -84,6 +84,7 @@ __device__ __forceinline__ uint32_t bit_width32(uint32_t v) { return v ? 32u - (
 #ifndef IXR_FUSED_CHUNKS
 #define IXR_FUSED_CHUNKS 4      // 16-byte chunks per lane and step of k_str_fused
 #endif
+constexpr uint32_t kLongStream = 16384;     // values of a DELTA stream from which a wave (k_parse_long), not a lane, follows it in large launches
 constexpr int kParseLaneThreshold = 32768;  // packs per launch from which k_parse_lanes is used (plans of mostly string packs: earlier)
 constexpr uint32_t kWin = 4096;
 constexpr uint32_t kWinAlloc = kWin + 16;  // bytes of LDS per window: data and 16 spare bytes so that 12-byte peeks never run off
@@ -937,7 +938,10 @@ __global__ __launch_bounds__(256) void k_parse_lanes(const DevPack* __restrict__
     int64_t first = 0;
     if (!err) {
         const StreamDesc sd = k == 0 ? m.s[0] : m.s[1];
-        if (k < 2 && sd.n) {
+        if (k < 2 && sd.n >= kLongStream) {
+            // left to k_parse_long: a lane that follows a stream of hundreds of blocks through global memory holds its whole
+            // wave, and the launch, for milliseconds
+        } else if (k < 2 && sd.n) {
             int64_t* md = (int64_t*)(scratch + (k == 0 ? P.s_idx[0] : P.s_idx[1]));
             uint32_t* mb = (uint32_t*)(md + (P.obj_count + kBlock - 1) / kBlock);
             werr = lane_walk_delta(base, psz, sd.in_off, sd.n, W ? W : 32, md, mb, &first, active);
@@ -956,6 +960,35 @@ __global__ __launch_bounds__(256) void k_parse_lanes(const DevPack* __restrict__
         if (!err) err = e0 ? e0 : (e1 ? e1 : e2);
         m.status = err ? err : (int32_t)consumed;
         metas[pi] = m;
+    }
+}
+
+// k_parse_long: the DELTA streams k_parse_lanes leaves out (kLongStream values and more: dictionaries of tens of thousands of
+// entries), one WAVE per stream with the window walker: guessed rounds take streams of one block size 64 blocks at a time, the
+// scalar chain takes the others at 0.4 us per block instead of a trip to memory per block.  Launched right behind
+// k_parse_lanes over the same packs; it completes the records that kernel wrote (first value, status on error).
+template <class DeltaWin>
+__global__ __launch_bounds__(128) void k_parse_long(const DevPack* __restrict__ packs, const int* __restrict__ list,
+                                                    PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
+                                                    uint8_t* __restrict__ scratch) {
+    __shared__ __align__(16) uint8_t s_dwin[2][DeltaWin::kAlloc];
+    __shared__ uint2 s_blk[2][65];
+    const int k = threadIdx.x >> 6;  // wave = stream
+    const int pi = list[pack_slot_remap(blockIdx.x, gridDim.x)];
+    PackMeta& M = metas[pi];
+    if (M.status < 0) return;
+    const StreamDesc sd = M.s[k];
+    if (sd.n < kLongStream) return;  // walked by its lane
+    const DevPack P = packs[pi];
+    DeltaWin w;
+    w.init(in + P.in_off, (uint32_t)P.pack_size, s_dwin[k]);
+    int64_t* md = (int64_t*)(scratch + P.s_idx[k]);
+    uint32_t* mb = (uint32_t*)(md + (P.obj_count + kBlock - 1) / kBlock);
+    int64_t first = 0;
+    const int32_t werr = walk_delta(w, (uint32_t)P.pack_size, sd.in_off, sd.n, P.width ? P.width : 32, md, mb, &first, s_blk[k]);
+    if ((threadIdx.x & 63) == 0) {
+        M.s[k].first = first;
+        if (werr) M.status = werr;  // both waves may report: either error stands for the pack
     }
 }
 
@@ -3583,6 +3616,7 @@ void launch_parse(const LaunchCtx& c, const int* list, int count) {
     if (count >= lanes_from) {
         hipLaunchKernelGGL(k_parse_lanes, dim3(cdiv((unsigned)count * 4, 256)), dim3(256), 0, c.stream, c.packs, list, count, c.metas,
                            c.in, c.scratch);
+        hipLaunchKernelGGL(k_parse_long<Win>, dim3((unsigned)count), dim3(128), 0, c.stream, c.packs, list, c.metas, c.in, c.scratch);
         return;
     }
     if (count < 1024)
