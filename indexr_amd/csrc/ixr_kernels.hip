@@ -964,32 +964,38 @@ __global__ __launch_bounds__(256) void k_parse_lanes(const DevPack* __restrict__
 }
 
 // k_parse_long: the DELTA streams k_parse_lanes leaves out (kLongStream values and more: dictionaries of tens of thousands of
-// entries), one WAVE per stream with the window walker: guessed rounds take streams of one block size 64 blocks at a time, the
+// entries), one WAVE per pack with the window walker: guessed rounds take streams of one block size 64 blocks at a time, the
 // scalar chain takes the others at 0.4 us per block instead of a trip to memory per block.  Launched right behind
 // k_parse_lanes over the same packs; it completes the records that kernel wrote (first value, status on error).
 template <class DeltaWin>
-__global__ __launch_bounds__(128) void k_parse_long(const DevPack* __restrict__ packs, const int* __restrict__ list,
-                                                    PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
-                                                    uint8_t* __restrict__ scratch) {
-    __shared__ __align__(16) uint8_t s_dwin[2][DeltaWin::kAlloc];
-    __shared__ uint2 s_blk[2][65];
-    const int k = threadIdx.x >> 6;  // wave = stream
+__global__ __launch_bounds__(64) void k_parse_long(const DevPack* __restrict__ packs, const int* __restrict__ list,
+                                                   PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
+                                                   uint8_t* __restrict__ scratch) {
+    // one wave per pack (its two streams one after the other; both long is rare: the length lists of a string dictionary with
+    // tens of thousands of entries): 4.6 KB of LDS, so that a compute unit holds as many walkers as it has wave slots
+    __shared__ __align__(16) uint8_t s_dwin[DeltaWin::kAlloc];
+    __shared__ uint2 s_blk[65];
     const int pi = list[pack_slot_remap(blockIdx.x, gridDim.x)];
     PackMeta& M = metas[pi];
     if (M.status < 0) return;
-    const StreamDesc sd = M.s[k];
-    if (sd.n < kLongStream) return;  // walked by its lane
+    const uint32_t n0 = M.s[0].n, n1 = M.s[1].n;
+    if (n0 < kLongStream && n1 < kLongStream) return;  // walked by their lanes
     const DevPack P = packs[pi];
-    DeltaWin w;
-    w.init(in + P.in_off, (uint32_t)P.pack_size, s_dwin[k]);
-    int64_t* md = (int64_t*)(scratch + P.s_idx[k]);
-    uint32_t* mb = (uint32_t*)(md + (P.obj_count + kBlock - 1) / kBlock);
-    int64_t first = 0;
-    const int32_t werr = walk_delta(w, (uint32_t)P.pack_size, sd.in_off, sd.n, P.width ? P.width : 32, md, mb, &first, s_blk[k]);
-    if ((threadIdx.x & 63) == 0) {
-        M.s[k].first = first;
-        if (werr) M.status = werr;  // both waves may report: either error stands for the pack
+    int32_t status = 0;
+    for (int k = 0; k < 2; k++) {
+        const StreamDesc sd = M.s[k];
+        if (sd.n < kLongStream) continue;
+        DeltaWin w;
+        w.init(in + P.in_off, (uint32_t)P.pack_size, s_dwin);
+        int64_t* md = (int64_t*)(scratch + P.s_idx[k]);
+        uint32_t* mb = (uint32_t*)(md + (P.obj_count + kBlock - 1) / kBlock);
+        int64_t first = 0;
+        const int32_t werr = walk_delta(w, (uint32_t)P.pack_size, sd.in_off, sd.n, P.width ? P.width : 32, md, mb, &first, s_blk);
+        if (threadIdx.x == 0) M.s[k].first = first;
+        if (werr && !status) status = werr;
+        DeltaWin::wave_lds_sync();  // the next stream starts with a fresh window
     }
+    if (threadIdx.x == 0 && status) M.status = status;
 }
 
 template <class DeltaWin>
@@ -3616,7 +3622,7 @@ void launch_parse(const LaunchCtx& c, const int* list, int count) {
     if (count >= lanes_from) {
         hipLaunchKernelGGL(k_parse_lanes, dim3(cdiv((unsigned)count * 4, 256)), dim3(256), 0, c.stream, c.packs, list, count, c.metas,
                            c.in, c.scratch);
-        hipLaunchKernelGGL(k_parse_long<Win>, dim3((unsigned)count), dim3(128), 0, c.stream, c.packs, list, c.metas, c.in, c.scratch);
+        hipLaunchKernelGGL(k_parse_long<Win>, dim3((unsigned)count), dim3(64), 0, c.stream, c.packs, list, c.metas, c.in, c.scratch);
         return;
     }
     if (count < 1024)
