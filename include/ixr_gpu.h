@@ -76,12 +76,12 @@ const char* ixr_last_error(void);
 int32_t ixr_device_count(void);
 
 /* Switches for A/B timing runs and for tests that must reach both variants of a kernel choice; no counterpart in the
- * reference, not for production use.  They start from the environment (IXR_SPLIT_STR, IXR_LANE_WALK_FROM, IXR_SLICE, read
+ * reference, not for production use.  They start from the environment (IXR_SPLIT_STR, IXR_WAVE_WALK_FROM, IXR_SLICE, read
  * once per process) and apply to plans created afterwards:
  *   "split_str"       1: string rows by the two-kernel form (per-row offsets through scratch), 0: the fused kernel
  *   "slice"           1 (default): sorted numeric dictionaries larger than 64 KB whose rows take the entries in order are decoded
  *                     per 1024-row tile and never written to scratch, 0: they go through scratch like every other dictionary
- *   "lane_walk_from"  packs per launch from which one lane instead of one wave follows a framing stream; 0 = built-in choice
+ *   "wave_walk_from"  packs per launch from which every framing stream is followed by a workgroup of one wave; 0 = built-in choice
  * Returns 0, or IXR_ERR_INVALID_ARGUMENT for an unknown name. */
 int32_t ixr_debug_switch(const char* name, int32_t value);
 

@@ -196,7 +196,7 @@ struct ixr_plan {
     uint64_t tot_in = 0, tot_out = 0, tot_rows = 0;
     bool profiling = false;
     bool overlap = true;  // numeric kernels on the auxiliary stream beside the string kernels (ixr_plan_set_overlap)
-    int lane_walk_from = 0;  // see LaunchCtx::lane_walk_from
+    int wave_walk_from = 0;  // see LaunchCtx::wave_walk_from
     bool slice = false;    // see LaunchCtx::slice
     bool fused_str = true; // string rows: index and body copy in one kernel (IXR_SPLIT_STR=1: two kernels with per-row offsets in scratch, for A/B runs)
     std::vector<TimedLaunch> timed;       // launches of the last run (profiling only)
@@ -242,10 +242,10 @@ namespace {
 struct EnvSwitches {
     std::atomic<int> split_str{0};       // IXR_SPLIT_STR=1: string rows by k_str_index + k_str_copy instead of k_str_bases + k_str_fused
     std::atomic<int> slice{1};           // IXR_SLICE=0: sorted numeric dictionaries taken in order go through scratch like the others (default: decoded per tile, the slice path of k_dict_num)
-    std::atomic<int> lane_walk_from{0};  // IXR_LANE_WALK_FROM=n: packs per launch from which the lane walker replaces the window walker
+    std::atomic<int> wave_walk_from{0};  // IXR_WAVE_WALK_FROM=n: packs per launch from which every stream is walked by a workgroup of one wave
     EnvSwitches() {
         if (const char* e = getenv("IXR_SPLIT_STR")) split_str = e[0] == '1';
-        if (const char* e = getenv("IXR_LANE_WALK_FROM")) lane_walk_from = atoi(e);
+        if (const char* e = getenv("IXR_WAVE_WALK_FROM")) wave_walk_from = atoi(e);
         if (const char* e = getenv("IXR_SLICE")) slice = e[0] != '0';
     }
 };
@@ -257,7 +257,7 @@ EnvSwitches& env_switches() {
 extern "C" int32_t ixr_debug_switch(const char* name, int32_t value) {
     if (!name) return fail(IXR_ERR_INVALID_ARGUMENT, "null switch name");
     if (!strcmp(name, "split_str")) env_switches().split_str = value != 0;
-    else if (!strcmp(name, "lane_walk_from")) env_switches().lane_walk_from = value;
+    else if (!strcmp(name, "wave_walk_from")) env_switches().wave_walk_from = value;
     else if (!strcmp(name, "slice")) env_switches().slice = value != 0;
     else return fail(IXR_ERR_INVALID_ARGUMENT, "unknown switch %s", name);
     return 0;
@@ -323,15 +323,7 @@ static ixr_plan* plan_create(int32_t device, const ixr_pack_desc* descs, int32_t
         pl->tot_in += (uint64_t)d.pack_size; pl->tot_out += (uint64_t)d.data_size; pl->tot_rows += (uint64_t)d.obj_count;
     }
     flush();
-    {
-        // String packs carry two DELTA length lists and, when mostly empty or repetitive, long RLE streams: on plans made
-        // mostly of them the lane walker overtakes the window walker earlier (100 M-row varchar table, 6104 packs: window
-        // walker 1.1 ms, lane walker 4.1; the window walker's time grows with the pack count, the lane walker's hardly).
-        int n_str = 0;
-        for (int i = 0; i < n_packs; i++) n_str += descs[i].data_type == IXR_STRING;
-        if (2 * n_str >= n_packs) pl->lane_walk_from = 20000;
-        if (env_switches().lane_walk_from) pl->lane_walk_from = env_switches().lane_walk_from;
-    }
+    if (env_switches().wave_walk_from) pl->wave_walk_from = env_switches().wave_walk_from;
     // one allocation: [index area of all packs][bulk area of the largest group]; make the bulk offsets absolute
     index_total = align16(index_total) + 64;  // the bulk area never starts at offset 0 (k_str_copy may read 15 bytes before a dictionary)
     for (int i = 0; i < n_packs; i++) {
@@ -491,7 +483,7 @@ extern "C" int32_t ixr_plan_run(ixr_plan* pl, const void* d_in, uint64_t in_byte
     if (pl->timed.size() > 200000) { pl->timed.clear(); pl->event_used = 0; }
     Timer T{pl, st}, TB{pl, pl->aux};
     LaunchCtx c{st, pl->d_packs, pl->d_metas, (const uint8_t*)d_in, (uint8_t*)d_out, pl->d_scratch};
-    c.lane_walk_from = pl->lane_walk_from;
+    c.wave_walk_from = pl->wave_walk_from;
     c.slice = pl->slice;
     LaunchCtx cb = c;
     cb.stream = pl->aux;

@@ -84,8 +84,7 @@ __device__ __forceinline__ uint32_t bit_width32(uint32_t v) { return v ? 32u - (
 #ifndef IXR_FUSED_CHUNKS
 #define IXR_FUSED_CHUNKS 4      // 16-byte chunks per lane and step of k_str_fused
 #endif
-constexpr uint32_t kLongStream = 16384;     // values of a DELTA stream from which a wave (k_parse_long), not a lane, follows it in large launches
-constexpr int kParseLaneThreshold = 32768;  // packs per launch from which k_parse_lanes is used (plans of mostly string packs: earlier)
+constexpr int kParseWaveThreshold = 2048;      // packs per launch from which every stream gets a workgroup of one wave (k_parse_waves)
 constexpr uint32_t kWin = 4096;
 constexpr uint32_t kWinAlloc = kWin + 16;  // bytes of LDS per window: data and 16 spare bytes so that 12-byte peeks never run off
 
@@ -340,8 +339,18 @@ __device__ __forceinline__ int64_t unzigzag64(uint64_t r) { return (int64_t)((r 
 // back to the serial chain until sizes repeat again.
 // The window is 16 KB where few packs are walked at a time (every stream's latency counts) and 4 KB in large launches
 // (more walkers fit a compute unit).
+// 16 bytes from global memory at any alignment, and byte i (0..15) of them
+__device__ __forceinline__ void ld16g(const uint8_t* p, uint64_t& lo, uint64_t& hi) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
+    hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+}
+__device__ __forceinline__ uint32_t byte_of(uint64_t lo, uint64_t hi, uint32_t i) {
+    return (uint32_t)((i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8))) & 0xFFu);
+}
 using DeltaWin = WinT<16384>;
-template <class DeltaWin>
+template <bool kFar, class DeltaWin>
 __device__ int32_t walk_delta(DeltaWin& w, uint32_t pack_size, uint32_t off, uint32_t n, int width, int64_t* min_delta, uint32_t* mb,
                               int64_t* first_out, uint2* s_blk) {
     const uint32_t lane = threadIdx.x & 63;
@@ -371,16 +380,33 @@ __device__ int32_t walk_delta(DeltaWin& w, uint32_t pack_size, uint32_t off, uin
         // ---- a round of guessed block starts
         if (guess && b0 < nfull) {
             const uint32_t want = min(64u, nfull - b0);
-            const uint32_t span = min(want * guess + block_max, DeltaWin::kBytes - 16u);
-            if (!w.has(pos, span)) w.load_n(pos, span);
-            // lanes whose block lies in the window if it has the guessed size (lane 0's does whatever its size: span >= block_max)
-            const uint32_t wend = w.w0 + w.len();
-            const uint32_t cover = min(want, (wend - pos - 16u) / guess);
-            const uint32_t g = pos + lane * guess;
+            // Where the window cannot hold a whole round (blocks of wide values: a kilobyte each at 64 bits), launches of few
+            // packs (kFar) do not bring the blocks into it: a round needs the few framing bytes of every block, not the values
+            // between them, and every lane fetches those from global memory itself (two round trips when the block's
+            // mini-blocks share one width, one more for every width byte that sits elsewhere): 64 blocks a round instead of
+            // the handful a window holds.  Launches that fill the chip with walkers keep to the window: they wait for
+            // memory throughput, not for a chain, and the scattered 16-byte reads cost more of it than whole windows
+            // (7 numeric columns x 1526 packs: 0.56 ms with windows, 0.62 with far rounds; one workgroup per pack: 1.05 / 0.89).
+            const bool far = kFar && (DeltaWin::kBytes - 32u) / guess < want;
+            uint32_t wend = 0xFFFFFFFFu, cover = want;
+            if (!far) {
+                const uint32_t span = min(want * guess + block_max, DeltaWin::kBytes - 16u);
+                if (!w.has(pos, span)) w.load_n(pos, span);
+                // lanes whose block lies in the window if it has the guessed size (lane 0's does whatever its size: span >= block_max)
+                wend = w.w0 + w.len();
+                cover = min(want, (wend - pos - 16u) / guess);
+            }
+            const uint32_t g = pos + lane * guess;  // pos < 2^24, a block is about a kilobyte at most
             const bool act = lane < cover;
             bool ok = act && g < end;
             const uint32_t gs = ok ? g : pos;  // lanes without a block read where lane 0 reads
-            const uint64_t lo = w.peek64(gs), hi = w.peek64(gs + 8);
+            uint64_t lo, hi;
+            if (far) {
+                ld16g(w.base + gs, lo, hi);  // gs < end <= pack size: the 16 bytes end inside the arena's slack
+            } else {
+                lo = w.peek64(gs);
+                hi = w.peek64(gs + 8);
+            }
             uint64_t v = 0;
             uint32_t used = 0;
             bool open = true, term = false;
@@ -395,12 +421,36 @@ __device__ int32_t walk_delta(DeltaWin& w, uint32_t pack_size, uint32_t off, uin
             ok = ok && term;
             uint32_t p = gs + used, idx[4];
             bool wide = false;
+            if (far) {
+                // the first width byte came with the varint (used <= 10); the other three are fetched where they are if all
+                // mini-blocks have the first one's width, and fetched again from their true place if not.  Nothing at or
+                // beyond `end` is read: such a block is not a sound one (its position ends beyond `end`).
+                const uint32_t bw0 = byte_of(lo, hi, used);
+                const uint32_t stride = 1u + 4u * min(bw0, W);
+                uint32_t spec[3];
 #pragma unroll
-            for (uint32_t m = 0; m < 4; m++) {
-                const uint32_t bw = w.lds[min(p - w.w0, w.len() + 15u)];  // a block that runs off the window is not a covered one
-                wide |= bw > W;
-                idx[m] = (p + 1) | (bw << 24);
-                p += 1 + 4 * min(bw, W);
+                for (uint32_t m = 0; m < 3; m++) {
+                    const uint32_t q = p + (m + 1u) * stride;
+                    spec[m] = q < end ? (uint32_t)w.base[q] : 0u;
+                }
+#pragma unroll
+                for (uint32_t m = 0; m < 4; m++) {
+                    uint32_t bw;
+                    if (m == 0) bw = p < end ? bw0 : 0u;
+                    else if (p == gs + used + m * stride) bw = spec[m - 1];
+                    else bw = p < end ? (uint32_t)w.base[p] : 0u;
+                    wide |= bw > W;
+                    idx[m] = (p + 1) | (bw << 24);
+                    p += 1 + 4 * min(bw, W);
+                }
+            } else {
+#pragma unroll
+                for (uint32_t m = 0; m < 4; m++) {
+                    const uint32_t bw = w.lds[min(p - w.w0, w.len() + 15u)];  // a block that runs off the window is not a covered one
+                    wide |= bw > W;
+                    idx[m] = (p + 1) | (bw << 24);
+                    p += 1 + 4 * min(bw, W);
+                }
             }
             const uint32_t size = p - gs;
             ok = ok && p <= end && p < (1u << 24);
@@ -409,7 +459,7 @@ __device__ int32_t walk_delta(DeltaWin& w, uint32_t pack_size, uint32_t off, uin
             uint32_t last = odd ? (uint32_t)__builtin_ctzll(odd) : cover - 1u;
             // a block of another size may run off the window (lane 0's cannot): then its widths were not read from the pack;
             // the round ends before it and the chain takes it
-            if (last > 0 && (uint32_t)__builtin_amdgcn_readlane((int)p, (int)last) + 16u > wend) {
+            if (!far && last > 0 && (uint32_t)__builtin_amdgcn_readlane((int)p, (int)last) + 16u > wend) {
                 last--;
                 guess = 0;
             }
@@ -423,9 +473,9 @@ __device__ int32_t walk_delta(DeltaWin& w, uint32_t pack_size, uint32_t off, uin
             }
             pos = (uint32_t)__builtin_amdgcn_readlane((int)p, (int)last);
             b0 += last + 1;
-            // a lone odd block in a long run keeps the guess; little accepted: back to the chain
-            if (last < 8u && last + 1u < cover) guess = 0;
-            serial_len = 64;
+            // a lone odd block in a long run keeps the guess; little accepted: back to the chain, for a few blocks at first (an
+            // odd block among equal ones is the common reason, and eight blocks behind it show the old size again)
+            if (last < 8u && last + 1u < cover) { guess = 0; serial_len = 8; }
             continue;
         }
         // ---- a round of the serial chain
@@ -527,7 +577,7 @@ __device__ int32_t walk_delta(DeltaWin& w, uint32_t pack_size, uint32_t off, uin
         const uint64_t differ = ~(same << (64u - cnt_r));
         const uint32_t streak = differ ? (uint32_t)__builtin_clzll(differ) : 64u;  // equal sizes from the round's last block down
         guess = (streak >= 4u && b1 < nfull) ? last_size : 0u;
-        serial_len = 64;
+        serial_len = min(64u, 2u * serial_len);  // no steady size in sight: longer rounds, fewer looks
         b0 = b1;
     }
     if (!err && pos != end) err = E_CORRUPT;
@@ -556,14 +606,10 @@ struct RleCand {
     uint32_t nrel;   // position of the following header, relative to the chunk's first byte (always > lane)
     bool packed, bad;
 };
-// The header a lane sees at stream position c0 + lane; `end` is one past the stream's last byte.  [c0, c0 + 76) must be
-// in the window.
-template <class WinX>
-__device__ __forceinline__ RleCand rle_candidate(const WinX& w, uint32_t c0, uint32_t end, uint32_t bw, uint32_t bytew,
-                                                 uint32_t vmask) {
-    const uint32_t lane = threadIdx.x & 63, pos = c0 + lane;
-    const uint64_t word = w.peek64(pos);
-    const uint32_t avail = pos < end ? min(5u, end - pos) : 0u;
+// The header whose first bytes are `word` (little-endian, 8 bytes from its position), `avail` of which belong to the stream
+// (0..5 matter).  nrel is left to the caller.
+__device__ __forceinline__ RleCand rle_header(uint64_t word, uint32_t avail, uint32_t bw, uint32_t bytew, uint32_t vmask,
+                                              uint32_t& payload) {
     // VarInteger.readUnsignedVarInt (VarInteger.java:68-81): seven bits per byte, the first byte without the top bit ends it
     const uint64_t term = ~word & 0x8080808080ull;
     const uint32_t nbr = term ? ((uint32_t)__builtin_ctzll(term) >> 3) + 1u : 6u;
@@ -577,7 +623,19 @@ __device__ __forceinline__ RleCand rle_candidate(const WinX& w, uint32_t c0, uin
     c.bad = nbr > avail || cnt > 65536u;  // the varint runs off the stream or has no end; more rows than a pack can hold
     c.cnt = min(cnt, 65536u);
     c.val = (uint32_t)(word >> (8u * c.nb)) & vmask;
-    const uint32_t payload = c.packed ? ((c.cnt + 7u) >> 3) * bw : bytew;
+    payload = c.packed ? ((c.cnt + 7u) >> 3) * bw : bytew;
+    c.nrel = 0;
+    return c;
+}
+// The header a lane sees at stream position c0 + lane; `end` is one past the stream's last byte.  [c0, c0 + 76) must be
+// in the window.
+template <class WinX>
+__device__ __forceinline__ RleCand rle_candidate(const WinX& w, uint32_t c0, uint32_t end, uint32_t bw, uint32_t bytew,
+                                                 uint32_t vmask) {
+    const uint32_t lane = threadIdx.x & 63, pos = c0 + lane;
+    const uint32_t avail = pos < end ? min(5u, end - pos) : 0u;
+    uint32_t payload;
+    RleCand c = rle_header(w.peek64(pos), avail, bw, bytew, vmask, payload);
     c.nrel = avail ? lane + c.nb + payload : 64u + lane;
     return c;
 }
@@ -608,7 +666,43 @@ __device__ int32_t walk_rle(Win& w, uint32_t off, uint32_t len, uint32_t n, uint
     const uint32_t bytew = (bw + 7) >> 3;
     const uint32_t vmask = (1u << (8 * bytew)) - 1u;
     uint32_t o = 0;
+    uint32_t guess = 0;  // bytes of a segment (header and payload) to try next, 0: look at the next 64 bytes
     while (pos < end) {
+        if (guess) {
+            // ---- a round of guessed headers.  Ids without runs come as bit-packed segments of one length (the writer closes a
+            // segment at 63 groups of 8 values: a kilobyte at 16 bits), far more than 64 bytes apart: a chunk then holds one
+            // header and a round advances by one segment.  When that happened, lane l assumes that a header sits at
+            // pos + l * guess and parses the 8 bytes there, fetched from global memory; lane 0's header is real, lane l's when
+            // every lane before it found a sound segment of exactly `guess` bytes.  The round takes the lanes up to and
+            // including the first with another size: up to 64 segments for the price of one trip to memory.
+            const uint32_t g = pos + lane * guess;  // guess <= 5 + 8192 * 32, pack offsets < 2^31: no overflow
+            const bool in = g < end;
+            uint64_t word = 0;
+            if (in) __builtin_memcpy(&word, w.base + g, 8);  // g < end <= pack size: the 8 bytes end inside the arena's slack
+            uint32_t payload;
+            const RleCand c = rle_header(word, in ? min(5u, end - g) : 0u, bw, bytew, vmask, payload);
+            const uint32_t size = c.nb + payload;
+            const bool sound = in && !c.bad && g + size <= end;
+            const uint64_t odd = __builtin_amdgcn_ballot_w64(!(sound && size == guess));
+            uint32_t last = odd ? (uint32_t)__builtin_ctzll(odd) : 63u;
+            // the lane behind a run of sound segments starts at or before `end`; at `end` the stream is over (lane 0 is inside)
+            if (!__builtin_amdgcn_readlane((int)in, (int)last)) last--;
+            const bool mine = lane <= last;
+            const uint32_t rows = mine ? c.cnt : 0u;
+            const uint32_t inc = wave_incl_scan(rows);
+            const uint32_t first = o + inc - rows;
+            const bool bad = mine && (!sound || first + rows > n);
+            if (__builtin_amdgcn_ballot_w64(bad)) return E_CORRUPT;
+            if (mine && rows) {
+                const uint32_t dp = g + c.nb;
+                const uint4 rec = make_uint4(c.packed ? dp : dp + bytew, first, rows, c.packed ? 1u : (c.val << 1));
+                for (uint32_t t = (first + kRleTile - 1) / kRleTile; t * (uint32_t)kRleTile < first + rows; t++) restart[t] = rec;
+            }
+            o += __builtin_amdgcn_readlane((int)inc, 63);
+            pos = (uint32_t)__builtin_amdgcn_readlane((int)(g + size), (int)last);
+            if (last < 8u) guess = 0;  // little taken: look at the bytes again
+            continue;
+        }
         if (!w.has(pos, 80u)) w.load(pos);
         const RleCand c = rle_candidate(w, pos, end, bw, bytew, vmask);
         uint32_t exit_rel;
@@ -628,6 +722,8 @@ __device__ int32_t walk_rle(Win& w, uint32_t off, uint32_t len, uint32_t n, uint
         }
         o += __builtin_amdgcn_readlane((int)inc, 63);
         pos += exit_rel;
+        // one header in the chunk and the next one far away: try whole segments of that size next
+        if (mask == 1ull && exit_rel >= 256u) guess = exit_rel;
     }
     return o != n ? E_CORRUPT : 0;  // Preconditions.checkState(valIndex == valCount) :126
 }
@@ -764,238 +860,63 @@ __device__ __forceinline__ void pack_header(const DevPack& P, const uint8_t* bas
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_parse_lanes: the same walk with one LANE per stream (4 lanes per pack), reading the framing bytes straight from
-// global memory.  Every step of a chain pays a memory round trip, but a launch over tens of thousands of packs keeps
-// hundreds of thousands of independent chains in flight, which wins over the window version's faster steps once the
-// chip is oversubscribed with walker waves.  The launcher picks by batch size.
+// The framing walk of launches of thousands of packs, in two kernels.  k_parse_head: one thread per pack derives the
+// record (kind, geometry, where the streams start; status = bytes the framing claims, or the header's error).
+// k_parse_waves: one WAVE (a workgroup of its own) per stream with the window walkers, grid (packs, 3): stream 0 and 1 the
+// DELTA streams, stream 2 the id stream.  It completes the records (first value, status on error: the walkers know one
+// error code, so the waves of a pack cannot disagree about it).  A walker holds one wave slot and 4.6 KB of LDS, where the
+// workgroup-per-pack form holds four wave slots and three windows whatever the pack has: a compute unit carries four
+// times the chains (7 numeric columns x 1526 packs: 1.03 -> 0.56 ms; 24 416 string packs: 1.76 ms).
+// (One LANE per stream, reading the framing from global memory, was the form for tens of thousands of packs before: every
+// step of a chain then pays a trip to memory, and the launch waits for the longest chain: 4.3 ms on those 24 416 string
+// packs, 1.58 against 1.40 ms on the 76 296 packs of the mixed table.)
 // ---------------------------------------------------------------------------------------------------------------
-struct Walker {
-    const uint8_t* base;  // pack start
-    uint32_t pos;         // current offset in the pack
-    uint32_t end;         // one past the last readable offset of the current stream
-    int32_t err;
-    __device__ __forceinline__ uint32_t u8() {
-        if (pos >= end) { err = E_CORRUPT; return 0; }
-        return base[pos++];
-    }
-    // VarInteger.readUnsignedVarInt / readUnsignedVarLong (VarInteger.java:68-96); at most 5 / 10 bytes
-    __device__ __forceinline__ uint64_t uvarint(int max_bytes) {
-        uint64_t v = 0;
-        int shift = 0;
-        for (int i = 0; i < max_bytes; i++) {
-            uint32_t b = u8();
-            v |= (uint64_t)(b & 0x7F) << shift;
-            if (!(b & 0x80)) return v;
-            shift += 7;
-        }
-        err = E_CORRUPT;
-        return v;
-    }
-};
-
-
-// Walk one DELTA stream (DeltaCodec.decodeInts/decodeLongs framing, DeltaCodec.java:100-141, 204-245) and write its index.
-// A block is a varint and four width bytes, each behind the mini-block the previous byte sizes: five dependent memory
-// round trips.  Streams mostly keep one width for a whole block, so the walk fetches a block's header as 16 bytes (the
-// varint and the first width byte), and in the same round trip the three bytes where the other width bytes are if every
-// mini-block has the first one's width, plus the 16 bytes where the next block then starts.  A byte is used only when
-// the walk arrives at exactly the position it was fetched from; any other position is read again.  One round trip per
-// block when the guess holds, never more than before when it does not.
-__device__ __forceinline__ void ld16g(const uint8_t* p, uint64_t& lo, uint64_t& hi) {
-    uint4 v;
-    __builtin_memcpy(&v, p, 16);
-    lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
-    hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
-}
-__device__ __forceinline__ uint32_t byte_of(uint64_t lo, uint64_t hi, uint32_t i) {
-    return (uint32_t)((i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8))) & 0xFFu);
-}
-__device__ int32_t lane_walk_delta(const uint8_t* base, uint32_t pack_size, uint32_t off, uint32_t n, int width,
-                              int64_t* min_delta, uint32_t* mb, int64_t* first_out, bool write) {
-    if (off + 4 > pack_size) return E_CORRUPT;
-    const int32_t len = (int32_t)ld32u(base + off);
-    if (len < 0 || (uint64_t)off + 4 + (uint64_t)len > pack_size) return E_CORRUPT;
-    uint32_t pos = off + 4;
-    const uint32_t end = off + 4 + (uint32_t)len;
-    const uint32_t vb = width == 32 ? 5 : 10;
-    // VarInteger.readUnsignedVarInt / readUnsignedVarLong (VarInteger.java:68-96) out of a 16-byte window that holds
-    // `avail` bytes of the stream; 0 bytes consumed = the stream ended inside the varint or it has more than vb bytes
-    auto varint = [&](uint64_t lo, uint64_t hi, uint32_t avail, uint32_t& used) {
-        uint64_t v = 0;
-        used = 0;
-        for (uint32_t i = 0; i < vb && i < avail; i++) {
-            const uint32_t b = byte_of(lo, hi, i);
-            v |= (uint64_t)(b & 0x7F) << (7 * i);
-            if (!(b & 0x80)) { used = i + 1; break; }
-        }
-        return v;
-    };
-    uint64_t lo, hi;
-    uint32_t used;
-    if (pos >= end) return E_CORRUPT;
-    ld16g(base + pos, lo, hi);
-    uint64_t raw = varint(lo, hi, min(16u, end - pos), used);
-    if (!used) return E_CORRUPT;
-    pos += used;
-    *first_out = width == 32 ? unzigzag32(raw) : unzigzag64(raw);
-    const uint32_t nb = (n + kBlock - 1) / kBlock;
-    bool have = false;  // lo / hi already hold the 16 bytes at pos
-    for (uint32_t b = 0; b < nb; b++) {
-        if (pos >= end) return E_CORRUPT;
-        if (!have) ld16g(base + pos, lo, hi);
-        have = false;
-        raw = varint(lo, hi, min(16u, end - pos), used);
-        if (!used) return E_CORRUPT;
-        if (write) min_delta[b] = width == 32 ? unzigzag32(raw) : unzigzag64(raw);
-        pos += used;
-        const uint32_t cnt = min((uint32_t)kBlock, n - b * kBlock);
-        // first mini-block: its width byte follows the varint inside the window (used <= 10)
-        if (pos >= end) return E_CORRUPT;
-        uint32_t bw = byte_of(lo, hi, used);
-        pos++;
-        if (bw > (uint32_t)width || pos >= (1u << 24)) return E_CORRUPT;
-        if (write) mb[b * 4] = pos | (bw << 24);
-        pos += ((min((uint32_t)kMini, cnt) + 7) >> 3) * bw;
-        if (pos > end) return E_CORRUPT;
-        // the guess: the other mini-blocks are full and as wide as the first
-        const uint32_t stride = 1 + (kMini / 8) * bw;
-        const uint32_t p1 = pos, p4 = pos + 3 * stride;
-        uint32_t spec[3] = {0, 0, 0};
-        uint64_t nlo = 0, nhi = 0;
-        const bool full = cnt == (uint32_t)kBlock;
-        if (full) {
-#pragma unroll
-            for (int k = 0; k < 3; k++)
-                if (p1 + k * stride < end) spec[k] = base[p1 + k * stride];
-            if (p4 < end) ld16g(base + p4, nlo, nhi);
-        }
-#pragma unroll
-        for (uint32_t m = 1; m < 4; m++) {
-            if (m * kMini >= cnt) break;
-            const uint32_t c = min((uint32_t)kMini, cnt - m * kMini);
-            if (pos >= end) return E_CORRUPT;
-            bw = (full && pos == p1 + (m - 1) * stride) ? spec[m - 1] : base[pos];
-            pos++;
-            if (bw > (uint32_t)width || pos >= (1u << 24)) return E_CORRUPT;
-            if (write) mb[b * 4 + m] = pos | (bw << 24);
-            pos += ((c + 7) >> 3) * bw;
-            if (pos > end) return E_CORRUPT;
-        }
-        if (full && pos == p4 && p4 < end) { lo = nlo; hi = nhi; have = true; }
-    }
-    return pos != end ? E_CORRUPT : 0;
-}
-
-// Walk the RLE/bit-packing hybrid id stream (RLEPackingHybridCodec.decodeInts, RLEPackingHybridCodec.java:97-128) and
-// record, for every tile of kRleTile rows, the segment header that covers the tile's first row.
-__device__ int32_t lane_walk_rle(const uint8_t* base, uint32_t off, uint32_t len, uint32_t n, uint32_t bw, uint4* restart, bool write) {
-    Walker w{base, off + 4, off + 4 + len, 0};
-    const uint32_t bytew = (bw + 7) >> 3;
-    uint32_t o = 0, next_tile = 0;
-    while (w.pos < w.end) {
-        uint32_t h = (uint32_t)w.uvarint(5);
-        if (w.err) break;
-        uint32_t cnt = h >> 1;
-        uint64_t payload = (h & 1) ? (uint64_t)((cnt + 7) >> 3) * bw : bytew;
-        if ((uint64_t)w.pos + payload > w.end || cnt > n - o) { w.err = E_CORRUPT; break; }
-        if (cnt && next_tile * (uint32_t)kRleTile < o + cnt) {
-            uint32_t val = 0;
-            if (!(h & 1)) for (uint32_t k = 0; k < bytew; k++) val |= (uint32_t)base[w.pos + k] << (8 * k);
-            const uint4 rec = make_uint4((h & 1) ? w.pos : w.pos + bytew, o, cnt, (h & 1) ? 1u : (val << 1));
-            while (next_tile * (uint32_t)kRleTile < o + cnt) {
-                if (write) restart[next_tile] = rec;
-                next_tile++;
-            }
-        }
-        o += cnt;
-        w.pos += (uint32_t)payload;
-    }
-    if (!w.err && o != n) w.err = E_CORRUPT;  // Preconditions.checkState(valIndex == valCount) :126
-    return w.err;
-}
-
-__global__ __launch_bounds__(256) void k_parse_lanes(const DevPack* __restrict__ packs, const int* __restrict__ list, int count,
-                                                     PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
-                                                     uint8_t* __restrict__ scratch) {
-    int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    int li = tid >> 2;
-    const int k = tid & 3;
-    const bool active = li < count;
-    if (!active) li = count - 1;  // keep the lane alive for the shuffles below; its writes are suppressed
+__global__ __launch_bounds__(256) void k_parse_head(const DevPack* __restrict__ packs, const int* __restrict__ list, int count,
+                                                    PackMeta* __restrict__ metas, const uint8_t* __restrict__ in) {
+    const int li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= count) return;
     const int pi = list[li];
     const DevPack P = packs[pi];
-    const uint8_t* base = in + P.in_off;
-    const uint32_t psz = (uint32_t)P.pack_size;
-    const uint32_t n = (uint32_t)P.obj_count;
-    const int W = P.width;
     PackMeta m;
     int32_t err;
     int64_t consumed;
     bool has_ids;
-    pack_header(P, base, m, err, consumed, has_ids);
-
-    int32_t werr = 0;
-    int64_t first = 0;
-    if (!err) {
-        const StreamDesc sd = k == 0 ? m.s[0] : m.s[1];
-        if (k < 2 && sd.n >= kLongStream) {
-            // left to k_parse_long: a lane that follows a stream of hundreds of blocks through global memory holds its whole
-            // wave, and the launch, for milliseconds
-        } else if (k < 2 && sd.n) {
-            int64_t* md = (int64_t*)(scratch + (k == 0 ? P.s_idx[0] : P.s_idx[1]));
-            uint32_t* mb = (uint32_t*)(md + (P.obj_count + kBlock - 1) / kBlock);
-            werr = lane_walk_delta(base, psz, sd.in_off, sd.n, W ? W : 32, md, mb, &first, active);
-        } else if (k == 2 && has_ids) {
-            werr = lane_walk_rle(base, m.ids_off, m.ids_len, n, m.id_bw, (uint4*)(scratch + P.s_restart), active);
-        }
-    }
-    // lane 0 of each group of 4 collects the results and writes the meta record
-    const int lane = threadIdx.x & 63;
-    const int g0 = lane & ~3;
-    int32_t e0 = __shfl(werr, g0), e1 = __shfl(werr, g0 + 1), e2 = __shfl(werr, g0 + 2);
-    int64_t f1 = __shfl(first, g0 + 1);
-    if (active && k == 0) {
-        m.s[0].first = first;
-        m.s[1].first = f1;
-        if (!err) err = e0 ? e0 : (e1 ? e1 : e2);
-        m.status = err ? err : (int32_t)consumed;
-        metas[pi] = m;
-    }
+    pack_header(P, in + P.in_off, m, err, consumed, has_ids);
+    m.status = err ? err : (int32_t)consumed;
+    metas[pi] = m;
 }
 
-// k_parse_long: the DELTA streams k_parse_lanes leaves out (kLongStream values and more: dictionaries of tens of thousands of
-// entries), one WAVE per pack with the window walker: guessed rounds take streams of one block size 64 blocks at a time, the
-// scalar chain takes the others at 0.4 us per block instead of a trip to memory per block.  Launched right behind
-// k_parse_lanes over the same packs; it completes the records that kernel wrote (first value, status on error).
 template <class DeltaWin>
-__global__ __launch_bounds__(64) void k_parse_long(const DevPack* __restrict__ packs, const int* __restrict__ list,
-                                                   PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
-                                                   uint8_t* __restrict__ scratch) {
-    // one wave per pack (its two streams one after the other; both long is rare: the length lists of a string dictionary with
-    // tens of thousands of entries): 4.6 KB of LDS, so that a compute unit holds as many walkers as it has wave slots
-    __shared__ __align__(16) uint8_t s_dwin[DeltaWin::kAlloc];
+__global__ __launch_bounds__(64) void k_parse_waves(const DevPack* __restrict__ packs, const int* __restrict__ list,
+                                                    PackMeta* __restrict__ metas, const uint8_t* __restrict__ in,
+                                                    uint8_t* __restrict__ scratch) {
+    static_assert(DeltaWin::kAlloc >= kWinAlloc, "one LDS window serves either walker");
+    __shared__ __align__(16) uint8_t s_win[DeltaWin::kAlloc];
     __shared__ uint2 s_blk[65];
+    const int k = blockIdx.y;
     const int pi = list[pack_slot_remap(blockIdx.x, gridDim.x)];
     PackMeta& M = metas[pi];
     if (M.status < 0) return;
-    const uint32_t n0 = M.s[0].n, n1 = M.s[1].n;
-    if (n0 < kLongStream && n1 < kLongStream) return;  // walked by their lanes
-    const DevPack P = packs[pi];
-    int32_t status = 0;
-    for (int k = 0; k < 2; k++) {
+    int32_t werr = 0;
+    if (k < 2) {
         const StreamDesc sd = M.s[k];
-        if (sd.n < kLongStream) continue;
+        if (!sd.n) return;
+        const DevPack P = packs[pi];
         DeltaWin w;
-        w.init(in + P.in_off, (uint32_t)P.pack_size, s_dwin);
+        w.init(in + P.in_off, (uint32_t)P.pack_size, s_win);
         int64_t* md = (int64_t*)(scratch + P.s_idx[k]);
         uint32_t* mb = (uint32_t*)(md + (P.obj_count + kBlock - 1) / kBlock);
         int64_t first = 0;
-        const int32_t werr = walk_delta(w, (uint32_t)P.pack_size, sd.in_off, sd.n, P.width ? P.width : 32, md, mb, &first, s_blk);
+        werr = walk_delta<false>(w, (uint32_t)P.pack_size, sd.in_off, sd.n, P.width ? P.width : 32, md, mb, &first, s_blk);
         if (threadIdx.x == 0) M.s[k].first = first;
-        if (werr && !status) status = werr;
-        DeltaWin::wave_lds_sync();  // the next stream starts with a fresh window
+    } else {
+        if (M.kind != K_DICT_NUM && M.kind != K_DICT_STR) return;
+        const DevPack P = packs[pi];
+        Win w;
+        w.init(in + P.in_off, (uint32_t)P.pack_size, s_win);
+        werr = walk_rle(w, M.ids_off, M.ids_len, (uint32_t)P.obj_count, M.id_bw, (uint4*)(scratch + P.s_restart));
     }
-    if (threadIdx.x == 0 && status) M.status = status;
+    if (threadIdx.x == 0 && werr) M.status = werr;
 }
 
 template <class DeltaWin>
@@ -1033,7 +954,7 @@ __global__ __launch_bounds__(256) void k_parse(const DevPack* __restrict__ packs
             w.init(base, psz, s_dwin[k]);
             int64_t* md = (int64_t*)(scratch + (k == 0 ? P.s_idx[0] : P.s_idx[1]));
             uint32_t* mb = (uint32_t*)(md + (P.obj_count + kBlock - 1) / kBlock);
-            werr = walk_delta(w, psz, sd.in_off, sd.n, W ? W : 32, md, mb, &first, s_blk[k]);
+            werr = walk_delta<true>(w, psz, sd.in_off, sd.n, W ? W : 32, md, mb, &first, s_blk[k]);
         } else if (k == 2 && has_ids) {
             Win w;
             w.init(base, psz, s_rwin);
@@ -3617,12 +3538,12 @@ static inline unsigned cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
 void launch_parse(const LaunchCtx& c, const int* list, int count) {
     if (count <= 0) return;
-    // below this many packs the chip is not full of walker waves and the faster steps of the window version win
-    const int lanes_from = c.lane_walk_from > 0 ? c.lane_walk_from : kParseLaneThreshold;
-    if (count >= lanes_from) {
-        hipLaunchKernelGGL(k_parse_lanes, dim3(cdiv((unsigned)count * 4, 256)), dim3(256), 0, c.stream, c.packs, list, count, c.metas,
-                           c.in, c.scratch);
-        hipLaunchKernelGGL(k_parse_long<Win>, dim3((unsigned)count), dim3(64), 0, c.stream, c.packs, list, c.metas, c.in, c.scratch);
+    // Thousands of packs: one wave per stream.  Fewer: one workgroup per pack, a wave per stream, all of them resident at
+    // once either way; with 16 KB windows when even those leave the chip mostly empty.
+    const int waves_from = c.wave_walk_from > 0 ? c.wave_walk_from : kParseWaveThreshold;
+    if (count >= waves_from) {
+        hipLaunchKernelGGL(k_parse_head, dim3(cdiv((unsigned)count, 256)), dim3(256), 0, c.stream, c.packs, list, count, c.metas, c.in);
+        hipLaunchKernelGGL(k_parse_waves<Win>, dim3((unsigned)count, 3), dim3(64), 0, c.stream, c.packs, list, c.metas, c.in, c.scratch);
         return;
     }
     if (count < 1024)

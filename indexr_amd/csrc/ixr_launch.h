@@ -19,7 +19,7 @@ struct LaunchCtx {
     uint8_t* scratch;      // scratch base of the current group
     int dict_only = 0;     // 1: build dictionaries only; packs whose decode writes straight to the output arena are skipped
     int slice = 0;         // 1: sorted numeric dictionaries whose rows take them in order are not materialised (slice path of k_dict_num)
-    int lane_walk_from = 0;  // framing walk: packs per launch from which one lane (not one wave) follows a stream; 0 = default
+    int wave_walk_from = 0;  // framing walk: packs per launch from which every stream has a one-wave workgroup of its own; 0 = default
 };
 
 // ---- the batch that allocates nothing: descriptors travel as a kernel argument, every working array lives in one

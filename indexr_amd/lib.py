@@ -145,7 +145,7 @@ EXPORTED_SYMBOLS = sorted(_sig)
 
 
 def debug_switch(name, value):
-    """ixr_debug_switch: A/B switches of the library ("split_str", "lane_walk_from"); they apply to plans created afterwards"""
+    """ixr_debug_switch: A/B switches of the library ("split_str", "slice", "wave_walk_from"); they apply to plans created afterwards"""
     rc = lib.ixr_debug_switch(name.encode(), int(value))
     if rc:
         raise IxrError(rc, "ixr_debug_switch(%s)" % name)

@@ -328,10 +328,11 @@ def test_corrupted_packs_fail_cleanly():
     assert status[0] == L.ERR_DATA_CORRUPTED
 
 
-def test_lane_walk_agrees_with_window_walk_on_corrupted_packs():
-    """Large batches (32768 packs and more) take the lane-per-stream framing walk.  Mutated packs (flips anywhere in the first
-    kilobyte: stream lengths, varints, mini-block width bytes, segment headers) must get the same status and the same
-    bytes from it as from the window walk of a small batch."""
+def test_large_launch_walk_agrees_with_small_launch_walk_on_corrupted_packs():
+    """Large batches (2048 packs and more) take the framing walk with a one-wave workgroup per stream, whose record is written
+    by one kernel and completed by another.  Mutated packs (flips anywhere in the first kilobyte: stream lengths, varints,
+    mini-block width bytes, segment headers) must get the same status and the same bytes from it as from the
+    workgroup-per-pack walk of a small batch."""
     r = rng(91)
     base = []
     for data_type in ALL_TYPES:
@@ -353,12 +354,9 @@ def test_lane_walk_agrees_with_window_walk_on_corrupted_packs():
     plan.destroy()
     filler = base[0]
     big = cases + [filler] * 2000
-    L.debug_switch("lane_walk_from", 1)  # looked at when a plan is created: this plan takes the lane walker whatever its size
-    try:
-        outs_b, status_b, plan = run_batch(big)
-        plan.destroy()
-    finally:
-        L.debug_switch("lane_walk_from", 0)
+    assert len(big) >= 2048  # the built-in choice, no switch
+    outs_b, status_b, plan = run_batch(big)
+    plan.destroy()
     assert len({int(x) for x in status_a}) > 3  # clean packs and more than one kind of failure
     for i, c in enumerate(cases):
         assert status_a[i] == status_b[i], (c.name, status_a[i], status_b[i])

@@ -2,9 +2,9 @@
 
 The id stream of a dictionary pack (RLEPackingHybridCodec.java:97-128) is walked 64 bytes at a time, every lane parsing a
 header at its byte; a DELTA stream (DeltaCodec.java:100-141, 204-245) in rounds of guessed block starts between rounds of the
-serial chain, out of a 16 KB window in small launches and a 4 KB window in large ones; large plans use one lane per stream.
-Every case here runs three ways -- a small launch, a launch of more than 1024 packs and the lane walker -- and must give the
-oracle's bytes and status each time.  Bar: bit-exact.
+serial chain, out of a 16 KB window in small launches and a 4 KB window in large ones.
+Every case here runs three ways -- a small launch, a launch of more than 1024 packs and the form of launches of thousands of
+packs, a one-wave workgroup per stream -- and must give the oracle's bytes and status each time.  Bar: bit-exact.
 """
 import os
 import struct
@@ -26,15 +26,16 @@ def three_ways(cases):
     """cases: Case objects whose `expect` is the oracle's output, or None when the oracle rejects the pack."""
     filler = oracle_case(np.arange(300, dtype="<i4") // 7, L.INT, O.DICT_COMPRESS, name="filler")
     runs = [("small launch", cases, None), ("large launch", cases + [filler] * (1100 - min(len(cases), 1000)), None),
-            ("lane walker", cases, "1")]
-    for label, batch, lanes in runs:
-        if lanes:
-            L.debug_switch("lane_walk_from", int(lanes))
+            ("a wave per stream", cases, "wave_walk_from")]
+    for label, batch, switch in runs:
+        if switch:
+            L.debug_switch(switch, 1)
         try:
             outs, status, plan = run_batch(batch)
             plan.destroy()
         finally:
-            L.debug_switch("lane_walk_from", 0)
+            if switch:
+                L.debug_switch(switch, 0)
         for c, out, st in zip(batch, outs, status):
             if c.expect is None:
                 assert st < 0, "%s, %s: the oracle rejects this pack, the GPU returned %d" % (label, c.name, st)
@@ -158,6 +159,35 @@ def test_broken_id_streams():
         variant("flip %d@%d" % (k, pos), lambda p, pos=pos, bit=bit: p.__setitem__(pos, p[pos] ^ bit))
     for cut in (1, 2, 3, 17, 64, 65):
         cases.append(judged_by_oracle(good[:len(good) - cut], L.INT, L.ENC_DICT_COMPRESS, n, 4 * n, "cut %d" % cut))
+    # Bit-packed segments of one length, a few hundred bytes apart (what the writer makes of ids without runs): the walker takes
+    # them by guessed header positions, 64 a round.  Flips in and around the headers, an odd segment in the middle, cuts.
+    segs = [("packed", [int(x) for x in r.integers(0, 300, 504)], 0) for _ in range(100)]
+    segs[41] = ("packed", [int(x) for x in r.integers(0, 300, 496)], 0)
+    segs[77] = ("run", 700, 5, 0)
+    steady, n2, _ = int_dict_pack(300, segs)
+    (body2,) = struct.unpack_from("<i", steady.tobytes(), ids_at)
+    headers, at = [], ids_at + 4   # where each segment's header starts (9-bit ids, run values in 2 bytes)
+    for seg in segs:
+        headers.append(at)
+        at += len(uvarint(seg[1] << 1)) + 2 if seg[0] == "run" else len(uvarint(len(seg[1]) << 1 | 1)) + (len(seg[1]) + 7) // 8 * 9
+    assert at == ids_at + 4 + body2 and headers[1] - headers[0] == 569
+
+    def variant2(name, edit):
+        p = bytearray(steady.tobytes())
+        edit(p)
+        cases.append(judged_by_oracle(np.frombuffer(bytes(p), np.uint8), L.INT, L.ENC_DICT_COMPRESS, n2, 4 * n2, name))
+
+    variant2("steady segments", lambda p: None)
+    variant2("steady, length word one short", lambda p: struct.pack_into("<i", p, ids_at, body2 - 1))
+    variant2("steady, length word one long", lambda p: struct.pack_into("<i", p, ids_at, body2 + 1))
+    for k in (0, 1, 2, 7, 8, 9, 30, 40, 63, 64, 65, 98):
+        hdr = headers[k]
+        for bit in (0, 1, 3, 7):
+            variant2("steady, header %d bit %d" % (k, bit), lambda p, hdr=hdr, bit=bit: p.__setitem__(hdr, p[hdr] ^ (1 << bit)))
+        variant2("steady, byte behind header %d" % k, lambda p, hdr=hdr: p.__setitem__(hdr + 1, p[hdr + 1] ^ 0x80))
+        variant2("steady, an id of segment %d" % k, lambda p, hdr=hdr: p.__setitem__(hdr + 20, p[hdr + 20] ^ 0x01))
+    for cut in (1, 2, 9, 500, 568, 569, 570, 5000):
+        cases.append(judged_by_oracle(steady[:len(steady) - cut], L.INT, L.ENC_DICT_COMPRESS, n2, 4 * n2, "steady cut %d" % cut))
     assert any(c.expect is None for c in cases) and any(c.expect is not None for c in cases)
     three_ways(cases)
 
@@ -214,8 +244,51 @@ def test_broken_delta_streams():
         q = p.copy()
         struct.pack_into("<i", q, 0, struct.unpack_from("<i", q.tobytes(), 0)[0] - 3)  # the stream's length word
         cases.append(judged_by_oracle(q, base.data_type, base.encode_type, base.n, base.data_size, base.name + " short length word"))
+    # Wide values: blocks of a kilobyte, whose framing bytes the guessed rounds fetch from global memory lane by lane.  Random
+    # flips mostly land in the values, so the width bytes and block minima are also hit on purpose.
+    for base in (oracle_case(r.integers(-2**63, 2**63 - 1, 65536, dtype=np.int64).astype("<i8"), L.LONG, O.DELTA, name="wide longs"),
+                 oracle_case(r.integers(-2**31, 2**31, 30000).astype("<i4"), L.INT, O.DELTA, name="wide ints"),
+                 oracle_case(np.cumsum(r.integers(0, 1 << 40, 50000).astype(np.int64)).astype("<i8"), L.LONG, O.DELTA, name="40 bit steps")):
+        cases.append(base)
+        p = base.pack
+        W = 64 if base.data_type == L.LONG else 32
+        framing = delta_framing_positions(p.tobytes(), base.n, W)
+        assert len(framing) >= 5 * (base.n // 128)
+        for k in range(40):
+            q = p.copy()
+            pos = framing[int(r.integers(0, len(framing)))] if k % 4 else int(r.integers(4, len(q)))
+            q[pos] ^= 1 << int(r.integers(0, 8))
+            cases.append(judged_by_oracle(q, base.data_type, base.encode_type, base.n, base.data_size, "%s flip%d@%d" % (base.name, k, pos)))
+        for cut in (1, 7, 300, 5000):
+            cases.append(judged_by_oracle(p[:len(p) - cut], base.data_type, base.encode_type, base.n, base.data_size, "%s cut %d" % (base.name, cut)))
     assert any(c.expect is None for c in cases)
     three_ways(cases)
+
+
+def delta_framing_positions(pack, n, W):
+    """Offsets of the framing bytes (block minima and width bytes) of a sound DELTA stream at the head of `pack`
+    (DeltaCodec.java:100-141, 204-245: length word, first value, then per 128 values a varint and four mini-blocks)."""
+    pos = 4
+    while pack[pos] & 0x80:
+        pos += 1
+    pos += 1
+    out, left = [], n
+    while left > 0:
+        while pack[pos] & 0x80:
+            out.append(pos)
+            pos += 1
+        out.append(pos)
+        pos += 1
+        cnt = min(128, left)
+        for m in range(4):
+            if m * 32 >= cnt:
+                break
+            c = min(32, cnt - m * 32)
+            out.append(pos)
+            pos += 1 + ((c + 7) // 8) * min(pack[pos], W)
+        left -= cnt
+    assert pos == 4 + struct.unpack_from("<i", pack, 0)[0], "the walk must end where the length word says"
+    return out
 
 
 # ------------------------------------------------------------------ string dictionaries: length table and one-pass scan

@@ -26,8 +26,8 @@ def short(name):
     m = re.match(r"(?:void )?(?:ixr::)?(k_\w+)(<[^>]*>)?", name)
     if not m:
         return None
-    if m.group(1) in ("k_parse", "k_parse_long"):  # k_parse<WinT<16384>> / k_parse<WinT<4096>>: the window walker, whatever its window
-        return m.group(1)
+    if m.group(1) in ("k_parse", "k_parse_head", "k_parse_waves"):  # the framing walk, whatever its launch form and window
+        return "k_parse"
     t = m.group(2) or ""
     t = t.replace("unsigned int", "u32").replace("unsigned long", "u64")
     t = re.sub(r",\s*\d+u?", "", t)  # k_delta<u64, 256> and k_delta<u64, 1024> are one kernel to the bench
